@@ -1,0 +1,214 @@
+/* seva_hip.h -- C-ABI of libseva_hip.so: the MI355X (gfx950) kernels behind the
+ * `seva.model` / `seva.sampling` operator API of Stable Virtual Camera.
+ *
+ * The reference (atakan-topaloglu/stable-virtual-camera) has no FFI layer: below its Python
+ * operator API sit PyTorch ATen ops.  This library sits exactly there.
+ * Each entry point names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated; no allocation, no ownership transfer;
+ *  - `seva_stream_t` is a hipStream_t; all work is enqueued on it, nothing synchronises;
+ *  - return 0 on success, a negative code on error; `seva_last_error()` gives the message
+ *    (thread-local);
+ *  - activations are channels-last: a (n, c, h, w) tensor of the reference is stored as
+ *    [n][h*w][c]; "f16" is IEEE binary16, "f32" binary32;
+ *  - all entry points are graph-capture safe (no sync, no malloc).
+ */
+#ifndef SEVA_HIP_H
+#define SEVA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* seva_stream_t;
+
+#define SEVA_OK 0
+#define SEVA_ERR_ARG (-1)
+#define SEVA_ERR_LAUNCH (-2)
+#define SEVA_ERR_UNSUPPORTED (-3)
+
+const char* seva_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int seva_abi_version(void);
+/* Name of the code object's target, e.g. "gfx950". */
+const char* seva_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM 3x3 convolution on fp16 MFMA with fp32 accumulation.
+ *   out[m][n] = sum_k A[m][k] * W[n][k]  (+ bias[n]) (+ row_add[m / rows_per_group][n])   [row pitch ld_row_add]
+ *                                        (+ residual[m][n])
+ * Replaces nn.Linear (seva/modules/transformer.py:11,30,52-57,187,200), nn.Conv2d 1x1/3x3
+ * (seva/modules/layers.py:40,55,101,106-108,113,118; seva/model.py:57,173), the nearest-2x
+ * upsample feeding a conv (layers.py:43-45), the GEGLU gate (transformer.py:13-15) and the
+ * residual / timestep-embedding adds fused into them (layers.py:133-138, transformer.py:107-109).
+ *
+ * mode 0 (plain): A is [M][lda] f16.
+ * mode 1 (conv3x3, pad 1): A is an NHWC f16 image [n][ih][iw][cin]; K = 9*cin ordered
+ *   (ky, kx, ci); M = n*oh*ow.  `stride` is 1 or 2.  `upsample`=1 applies the conv to the
+ *   nearest-neighbour 2x upsampling of A without materialising it (oh = 2*ih).
+ * epilogue 0: linear.  epilogue 1 (GEGLU): W rows are interleaved in groups of 64 as
+ *   [32 value rows | 32 gate rows] (same for bias); output has N/2 columns:
+ *   out[m][f] = (v + bv) * gelu_erf(g + bg).
+ * Requirements: K % 64 == 0, cin % 64 == 0 (mode 1), N % 4 == 0, all row pitches % 4 == 0,
+ * pointers 16-byte aligned.
+ */
+typedef struct seva_gemm_desc {
+  const void* a;
+  const void* w;         /* f16 [N][K] */
+  const float* bias;     /* [N] or NULL */
+  const float* row_add;  /* [ceil(M / rows_per_group)][ld_row_add] or NULL */
+  const float* residual; /* [M][ldr] or NULL */
+  float* out_f32;        /* [M][ldo32] or NULL */
+  void* out_f16;         /* [M][ldo16] or NULL */
+  int64_t M, N, K;
+  int64_t lda, ldr, ldo32, ldo16;
+  int64_t rows_per_group;
+  int64_t ld_row_add;    /* row pitch of row_add (>= N; 0 means N) */
+  int32_t mode;
+  int32_t epilogue;
+  int32_t n, ih, iw, cin, oh, ow, stride, upsample;
+} seva_gemm_desc;
+int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention, head dim 64, no mask, fp16 in/out, fp32 softmax.
+ * Replaces F.scaled_dot_product_attention under sdpa_kernel(FLASH_ATTENTION)
+ * (seva/modules/transformer.py:66-72) for the three regimes of SURVEY.md §2.1: per-frame,
+ * joint (view*h*w) and temporal (L = num_frames, batch = pixels).  The temporal regime reads
+ * the (b t) s c layout in place through strides instead of the transposes at
+ * transformer.py:149,154.
+ * Element (b0, b1, token l, head h, d) of q lives at q + b0*q_sb0 + b1*q_sb1 + l*q_sl + h*64 + d
+ * (strides in elements); k and v share strides; out likewise.
+ */
+typedef struct seva_attn_desc {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* out;
+  int64_t q_sb0, q_sb1, q_sl;
+  int64_t k_sb0, k_sb1, k_sl;
+  int64_t o_sb0, o_sb1, o_sl;
+  int32_t nb0, nb1;
+  int32_t heads;
+  int32_t lq, lk;
+  float scale;
+} seva_attn_desc;
+int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (fp32 statistics) over a channels-last tensor that may be the channel
+ * concatenation of two sources (the UNet skip concat, seva/model.py:206-207, is never
+ * materialised), optionally followed by SiLU and the Pluecker scale/shift modulation
+ *   y = silu(gn(x)) * (1 + scale) + shift,  [scale|shift] = dense_w @ dense[n][p][:] + dense_b
+ * Replaces GroupNorm32 + SiLU + dense_emb_layers of seva/modules/layers.py:61-63,98-100,
+ * 106-111,122-131, the output head norm (seva/model.py:171) and the transformer input norm
+ * (seva/modules/transformer.py:186,231).
+ * workspace: at least n * 64 * groups * 2 floats.
+ */
+typedef struct seva_groupnorm_desc {
+  const float* x1; /* [n][hw][c1] */
+  const float* x2; /* [n][hw][c2] or NULL */
+  const float* gamma;
+  const float* beta;    /* [c1 + c2] */
+  const float* dense;   /* [n][hw][dense_c] or NULL */
+  const float* dense_w; /* [2*(c1+c2)][dense_c] */
+  const float* dense_b; /* [2*(c1+c2)] */
+  void* out_f16;        /* [n][hw][c1+c2] */
+  float* workspace;
+  int32_t n, hw, c1, c2, groups, dense_c, silu;
+  float eps;
+} seva_groupnorm_desc;
+int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
+
+/* LayerNorm over the last dim, fp32 in, f16 out (nn.LayerNorm, transformer.py:102-104,124,141-143). */
+int seva_layernorm_f16(const float* x, const float* gamma, const float* beta, void* out_f16,
+                       int64_t rows, int32_t c, float eps, seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / elementwise helpers.
+ */
+/* [n][c][h][w] f32 (two sources concatenated on c; second may be NULL) -> [n][h*w][cpad] f16,
+ * channels >= c1+c2 zero-filled.  Replaces torch.cat at seva/model.py:227 + the NCHW->NLC
+ * rearranges (transformer.py:232). `scale` (per-n, may be NULL) multiplies source 1 (c_in of
+ * the denoiser, sampling.py:149). */
+int seva_nchw_to_nhwc_f16(const float* x1, int32_t c1, const float* x2, int32_t c2,
+                          const float* scale, void* out_f16, int32_t n, int32_t hw, int32_t cpad,
+                          seva_stream_t stream);
+/* [rows][ld] f32 channels-last -> [n][c][hw] f32 (first c channels). */
+int seva_nhwc_to_nchw_f32(const float* x, int64_t ld, float* out, int32_t n, int32_t c,
+                          int32_t hw, seva_stream_t stream);
+/* concat-cast: [rows][c1] f32 ‖ [rows][c2] f32 -> [rows][c1+c2] f16 (x2 may be NULL). */
+int seva_cast_concat_f16(const float* x1, int32_t c1, const float* x2, int32_t c2, void* out_f16,
+                         int64_t rows, seva_stream_t stream);
+/* Bilinear resize, align_corners=True, [n][c][sh][sw] f32 -> channels-last [n][oh*ow][c] f32
+ * (F.interpolate at seva/modules/layers.py:126-130; step-invariant). */
+int seva_bilinear_to_nhwc_f32(const float* src, float* out, int32_t n, int32_t c, int32_t sh,
+                              int32_t sw, int32_t oh, int32_t ow, seva_stream_t stream);
+/* Sinusoidal timestep embedding cos(t*f)||sin(t*f) (layers.py:11-32), f16 out [n][dim]; t is
+ * int64; freqs = exp(-ln(max_period) * arange(dim/2) / (dim/2)) as an f32 device table. */
+int seva_timestep_embedding_f16(const int64_t* t, const float* freqs, void* out_f16, int32_t n,
+                                int32_t dim, seva_stream_t stream);
+/* out = silu(x) as f16 (nn.SiLU before emb_layers / inside time_embed). */
+int seva_silu_f16(const float* x, void* out_f16, int64_t count, seva_stream_t stream);
+/* out[i] = a[i] + b[i] (SkipConnect, transformer.py:158-165), fp32. */
+int seva_add_f32(const float* a, const float* b, float* out, int64_t count, seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler elementwise (seva/sampling.py).  x tensors are [n][c][h][w] f32, `chw` = c*h*w.
+ */
+/* DiscreteDenoiser input blend, sampling.py:146-148:  out = x*(1-mask) + lat*mask, where
+ * replace = [n][c+1][hw] holds (lat, mask). */
+int seva_replace_blend_f32(const float* x, const float* replace, float* out, int32_t n, int32_t c,
+                           int32_t hw, seva_stream_t stream);
+/* out = net * c_out[n] + x * c_skip[n]  (sampling.py:149-152). */
+int seva_denoiser_combine_f32(const float* net, const float* x, const float* c_out,
+                              const float* c_skip, float* out, int32_t n, int64_t chw,
+                              seva_stream_t stream);
+/* x += eps * noise_scale[n]  (sampler_step, sampling.py:359-362); in-place allowed. */
+int seva_add_noise_f32(const float* x, const float* eps, const float* noise_scale, float* out,
+                       int32_t n, int64_t chw, seva_stream_t stream);
+/* CFG + Euler update in one pass (sampling.py:204-213,364-368):
+ *   den = u + scale[n]*(c - u);  d = (x - den)/sigma_hat[n];  out = x + dt[n]*d
+ * `den2` = [2n][chw] with the uncond half first. */
+int seva_cfg_euler_f32(const float* x, const float* den2, const float* scale,
+                       const float* sigma_hat, const float* dt, float* out, int32_t n, int64_t chw,
+                       seva_stream_t stream);
+
+/* Classifier-free guidance combine alone (ConstantGuidance, sampling.py:204-213):
+ *   out = u + scale[n]*(c - u), den2 = [2n][chw] with the uncond half first. */
+int seva_cfg_combine_f32(const float* den2, const float* scale, float* out, int32_t n, int64_t chw,
+                         seva_stream_t stream);
+/* Euler step alone (to_d + update, sampling.py:24-25,366-368): out = x + dt[n]*(x - den)/sigma[n]. */
+int seva_euler_step_f32(const float* x, const float* den, const float* sigma_hat, const float* dt,
+                        float* out, int32_t n, int64_t chw, seva_stream_t stream);
+/* d = (x - den)/sigma[n]  (to_d, sampling.py:24-25). */
+int seva_to_d_f32(const float* x, const float* den, const float* sigma, float* out, int32_t n,
+                  int64_t chw, seva_stream_t stream);
+/* out = x * s[n] (input * c_in, sampling.py:150); in-place allowed. */
+int seva_scale_rows_f32(const float* x, const float* s, float* out, int32_t n, int64_t chw,
+                        seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hipGraph helpers: capture everything enqueued on `stream` between begin/end, replay later.
+ */
+int seva_graph_begin(seva_stream_t stream);
+int seva_graph_end(seva_stream_t stream, void** graph_exec_out);
+int seva_graph_launch(void* graph_exec, seva_stream_t stream);
+int seva_graph_destroy(void* graph_exec);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
+ * Classes: 0 gemm, 1 conv, 2 attention, 3 norm, 4 elementwise.
+ */
+#define SEVA_PROF_CLASSES 5
+int seva_prof_enable(int on);
+/* Synchronises; fills ms[SEVA_PROF_CLASSES], launches[...], work[...] (flop or bytes); resets. */
+int seva_prof_collect(double* ms, int64_t* launches, double* work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEVA_HIP_H */

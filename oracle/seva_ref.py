@@ -175,11 +175,14 @@ def _sublayers(sd, prefix: str) -> list[int]:
     return sorted(idx)
 
 
-def _run_sequential(sd, prefix, x, emb, ctx, dense, num_frames, tname, joint_names):
-    """TimestepEmbedSequential dispatch, layers.py:66-83, keyed on which params exist."""
+def _run_sequential(sd, prefix, x, emb, ctx, dense, num_frames, tname, joint_names, trace=None):
+    """TimestepEmbedSequential dispatch, layers.py:66-83, keyed on which params exist.
+    `trace` (dict) receives every sub-layer's output keyed by its state_dict prefix."""
     ds_change = 0
     for j in _sublayers(sd, prefix):
         p = f"{prefix}.{j}"
+        if trace is not None and j > 0:
+            trace[f"{prefix}.{j - 1}"] = x
         if p + ".in_layers.0.weight" in sd:
             x = resblock(sd, p, x, emb, dense)
         elif p + ".proj_in.weight" in sd:
@@ -194,6 +197,8 @@ def _run_sequential(sd, prefix, x, emb, ctx, dense, num_frames, tname, joint_nam
             x = conv2d(sd, p, x)
         else:
             raise KeyError(f"oracle: cannot classify layer {p}")
+    if trace is not None:
+        trace[p] = x
     return x, ds_change
 
 
@@ -205,6 +210,7 @@ def seva_forward(
     dense_y: Tensor,
     num_frames: int,
     joint_names=("middle_ds8", "output_ds4", "output_ds2"),
+    trace: dict | None = None,
 ) -> Tensor:
     """Seva.forward, seva/model.py:176-216."""
     model_channels = sd["time_embed.0.weight"].shape[1]
@@ -215,18 +221,18 @@ def seva_forward(
     ds = 1
     for i in _sublayers(sd, "input_blocks"):
         h, dch = _run_sequential(
-            sd, f"input_blocks.{i}", h, emb, y, dense_y, num_frames, f"input_ds{ds}", joint_names
+            sd, f"input_blocks.{i}", h, emb, y, dense_y, num_frames, f"input_ds{ds}", joint_names, trace
         )
         if dch > 0:
             ds *= 2
         hs.append(h)
     h, _ = _run_sequential(
-        sd, "middle_block", h, emb, y, dense_y, num_frames, f"middle_ds{ds}", joint_names
+        sd, "middle_block", h, emb, y, dense_y, num_frames, f"middle_ds{ds}", joint_names, trace
     )
     for i in _sublayers(sd, "output_blocks"):
         h = torch.cat([h, hs.pop()], dim=1)
         h, dch = _run_sequential(
-            sd, f"output_blocks.{i}", h, emb, y, dense_y, num_frames, f"output_ds{ds}", joint_names
+            sd, f"output_blocks.{i}", h, emb, y, dense_y, num_frames, f"output_ds{ds}", joint_names, trace
         )
         if dch < 0:
             ds //= 2

@@ -1,0 +1,264 @@
+// Flash-style scaled-dot-product attention for head dim 64 on gfx950 (MI355X), fp16 in/out.
+//
+// One wave owns 32 query rows.  Scores are computed TRANSPOSED, S^T = K * Q^T with
+// v_mfma_f32_32x32x16_f16 (A = K rows from LDS, B = Q fragments kept in registers), so the query
+// sits on the lane and a lane's 16 accumulator registers per 32-key block are 16 keys of ITS
+// query: row max / row sum are register-local plus one exchange with lane^32.  The f32 scores,
+// exponentiated and packed to fp16 in place, are directly the B operand of the second product
+// O^T = V^T * P^T (accumulator-as-operand, k order permuted consistently on both operands); the
+// V^T fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16.  Online softmax
+// in the log2 domain, fp32 throughout.
+//
+// K tile: 128-byte rows, 16-byte chunk c of row r stored at c ^ ((r>>1)&7)  (conflict-free b128 row reads)
+// V tile: 128-byte rows, chunk c of row r stored at c ^ (((r>>1)&1)<<2)     (conflict-free tr reads)
+//
+// Regimes: per-frame / joint attention use 4 waves x 64-key tiles; the temporal
+// regime (L = num_frames <= 32, batch = pixels) uses one wave per (pixel, head) with a 32-key
+// tile and reads its tokens through the token stride, so no (b t) s c <-> (b s) t c transpose exists.
+#include "seva_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+struct AttnArgs {
+  const half_t* q;
+  const half_t* k;
+  const half_t* v;
+  half_t* out;
+  int64_t q_sb0, q_sb1, q_sl;
+  int64_t k_sb0, k_sb1, k_sl;
+  int64_t o_sb0, o_sb1, o_sl;
+  int32_t nb1, heads, lq, lk, qblocks;
+  float scale_log2;  // softmax scale * log2(e)
+};
+
+typedef short short8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ half8_t tr_read_pair(const char* a0, const char* a1) {
+  short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a0);
+  short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a1);
+  short8_t s = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(half8_t, s);
+}
+
+__device__ __forceinline__ int v_chunk_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
+__device__ __forceinline__ int k_chunk_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int NW, int KT, bool USE_TR>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int KB = KT / 32;               // 32-key blocks per tile
+  constexpr int PASSES = (KT * 8) / NT;     // 16-byte chunks per thread per tile (K and V each)
+  static_assert((KT * 8) % NT == 0, "tile/threads mismatch");
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128];
+  char* const lds_k = smem;
+  char* const lds_v = smem + KT * 128;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int qi = lane & 31, hh = lane >> 5;
+
+  // blockIdx.x = ((batch * heads) + head) * qblocks + qblock
+  int bid = blockIdx.x;
+  const int qb = bid % p.qblocks;
+  bid /= p.qblocks;
+  const int head = bid % p.heads;
+  const int batch = bid / p.heads;
+  const int b0 = batch / p.nb1, b1 = batch - b0 * p.nb1;
+
+  const half_t* const qbase = p.q + b0 * p.q_sb0 + b1 * p.q_sb1 + head * 64;
+  const half_t* const kbase = p.k + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
+  const half_t* const vbase = p.v + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
+  half_t* const obase = p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64;
+
+  const int qrow = qb * (32 * NW) + wave * 32 + qi;
+  const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+
+  half8_t qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    qf[s] = *(const half8_t*)(qbase + (int64_t)qrow_c * p.q_sl + 16 * s + 8 * hh);
+
+  f32x16 acc_o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nt = (p.lk + KT - 1) / KT;
+  uint4 kreg[PASSES], vreg[PASSES];
+  const int lc = tid & 7, lr = tid >> 3;  // chunk / row of this thread's staging slot
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      int key = kt * KT + lr + ps * (NT / 8);
+      if (key >= p.lk) key = p.lk - 1;
+      const int64_t off = (int64_t)key * p.k_sl + lc * 8;
+      kreg[ps] = *(const uint4*)(kbase + off);
+      vreg[ps] = *(const uint4*)(vbase + off);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int row = lr + ps * (NT / 8);
+      *(uint4*)(lds_k + row * 128 + (k_chunk_swz(row, lc) << 4)) = kreg[ps];
+      *(uint4*)(lds_v + row * 128 + (v_chunk_swz(row, lc) << 4)) = vreg[ps];
+    }
+  };
+
+  load_tile(0);
+  for (int kt = 0; kt < nt; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nt) load_tile(kt + 1);  // in flight during the math below
+
+    // ---- S^T = K Q^T ----
+    f32x16 sc[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+      const int krow = 32 * kb + qi;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8_t kf =
+            *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (log2 domain) ----
+    const bool partial = (kt + 1) * KT > p.lk;
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float t = sc[kb][r] * p.scale_log2;
+        if (partial) {
+          const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= p.lk) t = -1e30f;
+        }
+        sc[kb][r] = t;
+        mx = fmaxf(mx, t);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+    half8_t pf[KB][2];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e = __builtin_amdgcn_exp2f(sc[kb][8 * s2 + j] - m_new);
+          lsum += e;
+          pf[kb][s2][j] = (half_t)e;
+        }
+    l_run = l_run * alpha + lsum;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+    const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int r0 = 32 * kb + 16 * s2 + 4 * hh;
+          half8_t vf;
+          if (USE_TR) {
+            const int colbyte = (32 * db + 16 * (g16 & 1) + 4 * p4) * 2;
+            const int ch = colbyte >> 4, within = colbyte & 15;
+            const int ra = r0 + q4, rb = r0 + 8 + q4;
+            vf = tr_read_pair(lds_v + ra * 128 + (v_chunk_swz(ra, ch) << 4) + within,
+                              lds_v + rb * 128 + (v_chunk_swz(rb, ch) << 4) + within);
+          } else {
+            const int d = 32 * db + qi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int row = r0 + (j & 3) + 8 * (j >> 2);
+              vf[j] = *(const half_t*)(lds_v + row * 128 + (v_chunk_swz(row, d >> 3) << 4) + (d & 7) * 2);
+            }
+          }
+          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], acc_o[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < p.lq) {
+    half_t* const orow = obase + (int64_t)qrow * p.o_sl;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        half4_t h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[db][4 * t + r] * inv);
+        *(half4_t*)(orow + 32 * db + 8 * t + 4 * hh) = h;
+      }
+  }
+}
+
+template <int NW, int KT>
+int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr) {
+  AttnArgs args = a;
+  args.qblocks = (a.lq + 32 * NW - 1) / (32 * NW);
+  const int64_t nb = batch * a.heads * args.qblocks;
+  if (nb <= 0 || nb > 0x7fffffff) {
+    seva_set_error("attention: bad grid %lld", (long long)nb);
+    return SEVA_ERR_ARG;
+  }
+  if (use_tr)
+    hipLaunchKernelGGL((attn_kernel<NW, KT, true>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
+  else
+    hipLaunchKernelGGL((attn_kernel<NW, KT, false>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
+  return seva_check_launch("attn_kernel");
+}
+
+}  // namespace
+
+extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream) {
+  SEVA_REQUIRE(d != nullptr, "attention: null desc");
+  SEVA_REQUIRE(d->q && d->k && d->v && d->out, "attention: null pointer");
+  SEVA_REQUIRE(d->lq > 0 && d->lk > 0 && d->heads > 0 && d->nb0 > 0 && d->nb1 > 0,
+               "attention: empty problem lq=%d lk=%d heads=%d nb=%dx%d", d->lq, d->lk, d->heads,
+               d->nb0, d->nb1);
+  SEVA_REQUIRE(((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->out) % 16 == 0,
+               "attention: pointers must be 16-byte aligned");
+  SEVA_REQUIRE((d->q_sb0 | d->q_sb1 | d->q_sl | d->k_sb0 | d->k_sb1 | d->k_sl | d->o_sb0 |
+                d->o_sb1 | d->o_sl) % 8 == 0,
+               "attention: strides must be multiples of 8 elements");
+  AttnArgs a{};
+  a.q = (const half_t*)d->q; a.k = (const half_t*)d->k; a.v = (const half_t*)d->v;
+  a.out = (half_t*)d->out;
+  a.q_sb0 = d->q_sb0; a.q_sb1 = d->q_sb1; a.q_sl = d->q_sl;
+  a.k_sb0 = d->k_sb0; a.k_sb1 = d->k_sb1; a.k_sl = d->k_sl;
+  a.o_sb0 = d->o_sb0; a.o_sb1 = d->o_sb1; a.o_sl = d->o_sl;
+  a.nb1 = d->nb1; a.heads = d->heads; a.lq = d->lq; a.lk = d->lk;
+  a.scale_log2 = d->scale * 1.44269504088896340736f;
+  const int64_t batch = (int64_t)d->nb0 * d->nb1;
+  const char* no_tr = getenv("SEVA_ATTN_NO_TR");  // debug knob: scalar LDS reads instead of tr_b16
+  const bool use_tr = !(no_tr && no_tr[0] == '1');
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 4.0 * (double)batch * d->heads * (double)d->lq * (double)d->lk * 64.0;
+  SevaProfScope prof(2, flops, s);
+  if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr);
+  return launch<4, 64>(a, batch, s, use_tr);
+}

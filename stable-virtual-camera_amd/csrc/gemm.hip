@@ -1,0 +1,304 @@
+// fp16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   out[m][n] = sum_k A[m][k] * W[n][k] (+bias) (+row_add) (+residual)      (seva_hip.h)
+//
+// Structure: BMxBN output tile per 256-thread workgroup (4 waves as 2x2), K-tile 64 (128-byte LDS
+// rows), both operands staged by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction)
+// into a double-buffered LDS ring, one barrier per K-tile.  The LDS image is lane-linear; the
+// bank-conflict swizzle (16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7)) is applied on the
+// per-lane SOURCE address and again on the ds_read_b128 fragment reads.  MFMA is
+// v_mfma_f32_16x16x32_f16 with the WEIGHT fragment as the A operand, so each lane ends up with 4
+// consecutive output features of one row and the epilogue (bias, broadcast add, residual, GEGLU)
+// uses 8/16-byte vector accesses.
+//
+// The conv variant gathers the A tile straight from the NHWC image (per-lane source address per
+// (ky,kx) tap, zero page for padding, optional stride 2 or nearest-2x upsampled source), so
+// im2col / F.interpolate outputs never exist in HBM.
+#include "seva_common.h"
+
+namespace {
+
+constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
+
+__device__ uint4 g_zero_page[8];  // 128 B of zeros: source of padding taps (zero-initialised)
+
+struct GemmArgs {
+  const half_t* a;
+  const half_t* w;
+  const float* bias;
+  const float* row_add;
+  const float* residual;
+  float* out_f32;
+  half_t* out_f16;
+  int64_t M, N, K;
+  int64_t lda, ldr, ldo32, ldo16;
+  int64_t rows_per_group, ldra;
+  int32_t n, ih, iw, cin, oh, ow, stride, upsample;
+  int32_t tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0,
+                                   0);
+}
+
+// Bijective XCD-aware remap (blocks b, b+8, ... share an XCD): each XCD gets one contiguous run of
+// logical tiles, so the A row-panel it streams is fetched into that XCD's L2 once.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = bid & 7;
+  const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + (bid >> 3);
+}
+
+template <int BM, int BN, int MODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+  constexpr int WM = BM / 2, WN = BN / 2;  // per-wave tile
+  constexpr int MI = WM / 16, NJ = WN / 16;
+  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;  // 8-row wave-instructions per wave
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  static_assert(EPI == 0 || NJ == 4, "GEGLU epilogue needs a 64-wide wave tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [A buf0][A buf1][B buf0][B buf1]
+  char* const lds_a = smem;
+  char* const lds_b = smem + 2 * A_BYTES;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * BN;
+
+  // ---- staging state: lane (r = lane>>3, phys chunk = lane&7) of each 8-row wave-instruction ----
+  const int sr = lane >> 3, sp = lane & 7;
+  const half_t* a_ptr[A_PASSES];   // MODE 0: running source pointer
+  int a_by[A_PASSES], a_bx[A_PASSES];  // MODE 1: top-left input coords (conv-input space)
+  int64_t a_img[A_PASSES];             // MODE 1: element offset of image n
+  int a_q[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int row = wave * (BM / 4) + 8 * i + sr;  // row inside the tile
+    const int q = sp ^ ((row >> 1) & 7);           // logical 16-B chunk this lane fetches
+    a_q[i] = q;
+    int64_t m = m0 + row;
+    if (m >= p.M) m = p.M - 1;
+    if (MODE == 0) {
+      a_ptr[i] = p.a + m * p.lda + q * 8;
+      a_by[i] = a_bx[i] = 0;
+      a_img[i] = 0;
+    } else {
+      const int ohw = p.oh * p.ow;
+      const int img = (int)(m / ohw);
+      const int rem = (int)(m - (int64_t)img * ohw);
+      const int oy = rem / p.ow, ox = rem - oy * p.ow;
+      a_by[i] = oy * p.stride - 1;
+      a_bx[i] = ox * p.stride - 1;
+      a_img[i] = (int64_t)img * p.ih * p.iw * p.cin;
+      a_ptr[i] = nullptr;
+    }
+  }
+  const half_t* b_ptr[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int row = wave * (BN / 4) + 8 * i + sr;
+    const int q = sp ^ ((row >> 1) & 7);
+    int64_t n = n0 + row;
+    if (n >= p.N) n = p.N - 1;
+    b_ptr[i] = p.w + n * p.K + q * 8;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    char* const la = lds_a + buf * A_BYTES + wave * (BM / 4) * 128;
+    char* const lb = lds_b + buf * B_BYTES + wave * (BN / 4) * 128;
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) glds16(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
+    } else {
+      const int k0 = kt * BK;
+      const int tap = k0 / p.cin;  // block-uniform: a K-tile never straddles taps (cin % 64 == 0)
+      const int ci0 = k0 - tap * p.cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int eh = p.upsample ? 2 * p.ih : p.ih, ew = p.upsample ? 2 * p.iw : p.iw;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        const int iy = a_by[i] + ky, ix = a_bx[i] + kx;
+        const bool ok = (iy >= 0) & (iy < eh) & (ix >= 0) & (ix < ew);
+        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        const half_t* src = p.a + a_img[i] + ((int64_t)sy * p.iw + sx) * p.cin + ci0 + a_q[i] * 8;
+        const void* g = ok ? (const void*)src : (const void*)g_zero_page;
+        glds16(g, la + i * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) glds16(b_ptr[i] + (int64_t)kt * BK, lb + i * 1024);
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;  // fragment row / k-group
+  const int nk = (int)(p.K / BK);
+
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* const ta = lds_a + cur * A_BYTES;
+    const char* const tb = lds_b + cur * B_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8_t af[MI], bf[NJ];
+      const int q = 4 * s + fg;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WM + 16 * i + fr;
+        af[i] = *(const half8_t*)(ta + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = wn * WN + 16 * j + fr;
+        bf[j] = *(const half8_t*)(tb + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds features f..f+3 (rows of D) of token m (column of D) ----
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t m = m0 + wm * WM + 16 * i + fr;
+    if (m >= p.M) continue;
+    const int64_t grp = (p.row_add != nullptr) ? m / p.rows_per_group : 0;
+    if (EPI == 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+        if (f >= p.N) continue;
+        f32x4 v = acc[i][j];
+        if (p.bias) v += *(const f32x4*)(p.bias + f);
+        if (p.row_add) v += *(const f32x4*)(p.row_add + grp * p.ldra + f);
+        if (p.residual) v += *(const f32x4*)(p.residual + m * p.ldr + f);
+        if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v;
+        if (p.out_f16) {
+          half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+        }
+      }
+    } else {
+      // wave's 64 weight rows = [16 v | 16 v | 16 g | 16 g] -> 32 output features
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t fv = n0 + wn * WN + 16 * j + 4 * fg;  // interleaved-row index of the value
+        if (fv >= p.N) continue;
+        f32x4 v = acc[i][j], g = acc[i][j + 2];
+        if (p.bias) {
+          v += *(const f32x4*)(p.bias + fv);
+          g += *(const f32x4*)(p.bias + fv + 32);
+        }
+        const int64_t fo = (n0 + wn * WN) / 2 + 16 * j + 4 * fg;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = v[r] * gelu_erf_f(g[r]);
+        if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o;
+        if (p.out_f16) {
+          half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+          *(half4_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int MODE, int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = gemm_kernel<BM, BN, MODE, EPI>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  args.tiles_m = (int)((a.M + BM - 1) / BM);
+  args.tiles_n = (int)((a.N + BN - 1) / BN);
+  const int64_t nb = (int64_t)args.tiles_m * args.tiles_n;
+  if (nb <= 0 || nb > 0x7fffffff) {
+    seva_set_error("gemm: bad grid %lld", (long long)nb);
+    return SEVA_ERR_ARG;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, s, args);
+  return seva_check_launch("gemm_kernel");
+}
+
+}  // namespace
+
+extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
+  SEVA_REQUIRE(d != nullptr, "gemm: null desc");
+  SEVA_REQUIRE(d->a && d->w, "gemm: null operand");
+  SEVA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%lld N=%lld K=%lld",
+               (long long)d->M, (long long)d->N, (long long)d->K);
+  SEVA_REQUIRE(d->K % BK == 0, "gemm: K=%lld not a multiple of 64", (long long)d->K);
+  SEVA_REQUIRE(d->N % 4 == 0, "gemm: N=%lld not a multiple of 4", (long long)d->N);
+  SEVA_REQUIRE(d->out_f32 || d->out_f16, "gemm: no output");
+  SEVA_REQUIRE(d->mode == 0 || d->mode == 1, "gemm: bad mode %d", d->mode);
+  SEVA_REQUIRE(d->epilogue == 0 || d->epilogue == 1, "gemm: bad epilogue %d", d->epilogue);
+  SEVA_REQUIRE(!d->row_add || d->rows_per_group > 0, "gemm: row_add needs rows_per_group");
+  SEVA_REQUIRE(((uintptr_t)d->a | (uintptr_t)d->w | (uintptr_t)d->bias | (uintptr_t)d->row_add |
+                (uintptr_t)d->residual | (uintptr_t)d->out_f32 | (uintptr_t)d->out_f16) % 16 == 0,
+               "gemm: pointers must be 16-byte aligned");
+  SEVA_REQUIRE((!d->residual || d->ldr % 4 == 0) && (!d->out_f32 || d->ldo32 % 4 == 0) &&
+                   (!d->out_f16 || d->ldo16 % 4 == 0),
+               "gemm: row pitches must be multiples of 4");
+  GemmArgs a{};
+  a.a = (const half_t*)d->a;
+  a.w = (const half_t*)d->w;
+  a.bias = d->bias;
+  a.row_add = d->row_add;
+  a.residual = d->residual;
+  a.out_f32 = d->out_f32;
+  a.out_f16 = (half_t*)d->out_f16;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.lda = d->lda; a.ldr = d->ldr; a.ldo32 = d->ldo32; a.ldo16 = d->ldo16;
+  a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
+  a.ldra = d->ld_row_add > 0 ? d->ld_row_add : d->N;
+  SEVA_REQUIRE(a.ldra % 4 == 0, "gemm: ld_row_add must be a multiple of 4");
+  if (d->mode == 1) {
+    SEVA_REQUIRE(d->cin > 0 && d->cin % 64 == 0, "conv: cin=%d not a multiple of 64", d->cin);
+    SEVA_REQUIRE(d->K == 9LL * d->cin, "conv: K=%lld != 9*cin", (long long)d->K);
+    SEVA_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
+    SEVA_REQUIRE(!(d->upsample && d->stride != 1), "conv: upsample needs stride 1");
+    const int eh = d->upsample ? 2 * d->ih : d->ih, ew = d->upsample ? 2 * d->iw : d->iw;
+    SEVA_REQUIRE(d->oh == (eh + 2 - 3) / d->stride + 1 && d->ow == (ew + 2 - 3) / d->stride + 1,
+                 "conv: output %dx%d inconsistent with input %dx%d stride %d up %d", d->oh, d->ow,
+                 d->ih, d->iw, d->stride, d->upsample);
+    SEVA_REQUIRE(d->M == (int64_t)d->n * d->oh * d->ow, "conv: M != n*oh*ow");
+    a.n = d->n; a.ih = d->ih; a.iw = d->iw; a.cin = d->cin; a.oh = d->oh; a.ow = d->ow;
+    a.stride = d->stride; a.upsample = d->upsample;
+  } else {
+    SEVA_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda=%lld invalid", (long long)d->lda);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
+  SevaProfScope prof(d->mode == 1 ? 1 : 0, flops, s);
+  if (d->epilogue == 1) {
+    SEVA_REQUIRE(d->N % 64 == 0, "geglu: N=%lld not a multiple of 64", (long long)d->N);
+    SEVA_REQUIRE(d->mode == 0, "geglu: plain mode only");
+    return launch<128, 128, 0, 1>(a, s);
+  }
+  const bool narrow = d->N <= 32;
+  if (d->mode == 0) return narrow ? launch<128, 32, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
+  return narrow ? launch<128, 32, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
+}

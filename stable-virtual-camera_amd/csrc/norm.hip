@@ -1,0 +1,265 @@
+// GroupNorm (+SiLU, +Pluecker scale/shift modulation) and LayerNorm for channels-last fp32
+// activations, f16 outputs (the next GEMM's A operand).  HBM-bound: every thread moves 16-byte
+// vectors, a tensor is read twice (statistics, apply) and written once as f16.
+//
+// GroupNorm statistics are deterministic: per-slab partial sums (fixed thread->element map, fixed
+// reduction order) are written to a workspace and combined in double precision by the apply kernel.
+// The input may be the channel concatenation of two tensors (UNet skip concat), read in place.
+#include "seva_common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SLABS = 64;
+constexpr int GN_MAX_GROUPS = 32;
+constexpr int GN_MAX_DENSE = 8;
+
+struct GnArgs {
+  const float* x1;
+  const float* x2;
+  const float* gamma;
+  const float* beta;
+  const float* dense;
+  const float* dense_w;
+  const float* dense_b;
+  half_t* out;
+  float* ws;
+  int32_t n, hw, c1, c2, groups, dense_c, silu;
+  int32_t nslab_stats;  // slabs used by the statistics pass
+  float eps;
+};
+
+// thread -> (pixel lane, first quad); quads advance by `qstep`
+struct GnMap {
+  int cq, tpp, pl_count, pl, q0, qstep;
+  bool active;
+  __device__ GnMap(int C) {
+    cq = C >> 2;
+    tpp = cq < GN_THREADS ? cq : GN_THREADS;  // threads per pixel
+    pl_count = GN_THREADS / tpp;
+    const int t = threadIdx.x;
+    pl = t / tpp;
+    q0 = t - pl * tpp;
+    qstep = tpp;
+    active = pl < pl_count;
+  }
+};
+
+__device__ __forceinline__ f32x4 load_quad(const GnArgs& p, int n, int pix, int c) {
+  // channel c (multiple of 4) of pixel pix of image n, from whichever source holds it
+  if (c < p.c1) return *(const f32x4*)(p.x1 + ((int64_t)n * p.hw + pix) * p.c1 + c);
+  return *(const f32x4*)(p.x2 + ((int64_t)n * p.hw + pix) * p.c2 + (c - p.c1));
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [pl_count][C] sums, then sumsq
+  const int C = p.c1 + p.c2;
+  const GnMap mp(C);
+  const int n = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+  const int p_begin = (int)((int64_t)slab * p.hw / nslab);
+  const int p_end = (int)((int64_t)(slab + 1) * p.hw / nslab);
+  float* const lsum = lds;
+  float* const lsq = lds + mp.pl_count * C;
+  if (mp.active) {
+    for (int q = mp.q0; q < mp.cq; q += mp.qstep) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+      for (int pix = p_begin + mp.pl; pix < p_end; pix += mp.pl_count) {
+        const f32x4 v = load_quad(p, n, pix, q * 4);
+        s += v;
+        ss += v * v;
+      }
+      *(f32x4*)(lsum + mp.pl * C + q * 4) = s;
+      *(f32x4*)(lsq + mp.pl * C + q * 4) = ss;
+    }
+  }
+  __syncthreads();
+  const int g = threadIdx.x;
+  if (g < p.groups) {
+    const int cpg = C / p.groups;
+    float s = 0.f, ss = 0.f;
+    for (int pl = 0; pl < mp.pl_count; ++pl)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        s += lsum[pl * C + c];
+        ss += lsq[pl * C + c];
+      }
+    float* o = p.ws + (((int64_t)n * nslab + slab) * p.groups + g) * 2;
+    o[0] = s;
+    o[1] = ss;
+  }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
+  __shared__ float g_mean[GN_MAX_GROUPS], g_rstd[GN_MAX_GROUPS];
+  const int C = p.c1 + p.c2;
+  const GnMap mp(C);
+  const int n = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+  const int cpg = C / p.groups;
+  if ((int)threadIdx.x < p.groups) {
+    const int g = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int sl = 0; sl < p.nslab_stats; ++sl) {
+      const float* o = p.ws + (((int64_t)n * p.nslab_stats + sl) * p.groups + g) * 2;
+      s += (double)o[0];
+      ss += (double)o[1];
+    }
+    const double cnt = (double)cpg * (double)p.hw;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    g_mean[g] = (float)mean;
+    g_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  if (!mp.active) return;
+  const int p_begin = (int)((int64_t)slab * p.hw / nslab);
+  const int p_end = (int)((int64_t)(slab + 1) * p.hw / nslab);
+  const int dc = p.dense ? p.dense_c : 0;
+  for (int q = mp.q0; q < mp.cq; q += mp.qstep) {
+    const int c0 = q * 4;
+    float a[4], b[4], wsc[4][GN_MAX_DENSE], wsh[4][GN_MAX_DENSE], bsc[4], bsh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + r, g = c / cpg;
+      a[r] = g_rstd[g] * p.gamma[c];
+      b[r] = p.beta[c] - g_mean[g] * a[r];
+      bsc[r] = dc ? p.dense_b[c] : 0.f;
+      bsh[r] = dc ? p.dense_b[C + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < GN_MAX_DENSE; ++j) {
+        wsc[r][j] = (j < dc) ? p.dense_w[(int64_t)c * dc + j] : 0.f;
+        wsh[r][j] = (j < dc) ? p.dense_w[(int64_t)(C + c) * dc + j] : 0.f;
+      }
+    }
+    for (int pix = p_begin + mp.pl; pix < p_end; pix += mp.pl_count) {
+      const f32x4 v = load_quad(p, n, pix, c0);
+      float dn[GN_MAX_DENSE];
+      if (dc) {
+        const float* dp = p.dense + ((int64_t)n * p.hw + pix) * dc;
+#pragma unroll
+        for (int j = 0; j < GN_MAX_DENSE; ++j) dn[j] = (j < dc) ? dp[j] : 0.f;
+      }
+      half4_t h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float y = v[r] * a[r] + b[r];
+        if (p.silu) y = silu_f(y);
+        if (dc) {
+          float sc = bsc[r], sh = bsh[r];
+#pragma unroll
+          for (int j = 0; j < GN_MAX_DENSE; ++j) {
+            sc += wsc[r][j] * dn[j];
+            sh += wsh[r][j] * dn[j];
+          }
+          y = y * (1.0f + sc) + sh;
+        }
+        h[r] = (half_t)y;
+      }
+      *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+    }
+  }
+}
+
+constexpr int LN_MAXV = 5;  // float4 per lane -> C <= 1280
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        half_t* __restrict__ out, int64_t rows,
+                                                        int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int cq = c >> 2;
+  const float* xr = x + row * c;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < cq) {
+      v[k] = *(const f32x4*)(xr + i * 4);
+      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < cq) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[k][r] - mean;
+        ss += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+  half_t* orow = out + row * c;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < cq) {
+      const f32x4 g = *(const f32x4*)(gamma + i * 4);
+      const f32x4 b = *(const f32x4*)(beta + i * 4);
+      half4_t h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = (half_t)((v[k][r] - mean) * rstd * g[r] + b[r]);
+      *(half4_t*)(orow + i * 4) = h;
+    }
+  }
+}
+
+int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+}  // namespace
+
+extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream) {
+  SEVA_REQUIRE(d != nullptr, "groupnorm: null desc");
+  SEVA_REQUIRE(d->x1 && d->gamma && d->beta && d->out_f16 && d->workspace, "groupnorm: null pointer");
+  SEVA_REQUIRE(d->n > 0 && d->hw > 0 && d->c1 > 0 && d->c2 >= 0, "groupnorm: bad shape");
+  SEVA_REQUIRE(d->c2 == 0 || d->x2 != nullptr, "groupnorm: c2 > 0 needs x2");
+  const int C = d->c1 + d->c2;
+  SEVA_REQUIRE(d->c1 % 4 == 0 && d->c2 % 4 == 0, "groupnorm: c1=%d c2=%d must be multiples of 4", d->c1, d->c2);
+  SEVA_REQUIRE(d->groups > 0 && d->groups <= GN_MAX_GROUPS && C % d->groups == 0,
+               "groupnorm: %d channels / %d groups unsupported", C, d->groups);
+  SEVA_REQUIRE(!d->dense || (d->dense_c > 0 && d->dense_c <= GN_MAX_DENSE && d->dense_w && d->dense_b),
+               "groupnorm: bad dense modulation args (dense_c=%d)", d->dense_c);
+  SEVA_REQUIRE(C <= 4 * GN_THREADS * 4, "groupnorm: C=%d too large", C);
+  GnArgs a{};
+  a.x1 = d->x1; a.x2 = d->x2; a.gamma = d->gamma; a.beta = d->beta;
+  a.dense = d->dense; a.dense_w = d->dense_w; a.dense_b = d->dense_b;
+  a.out = (half_t*)d->out_f16; a.ws = d->workspace;
+  a.n = d->n; a.hw = d->hw; a.c1 = d->c1; a.c2 = d->c2; a.groups = d->groups;
+  a.dense_c = d->dense_c; a.silu = d->silu; a.eps = d->eps;
+  const int cq = C / 4;
+  const int tpp = cq < GN_THREADS ? cq : GN_THREADS;
+  const int plc = GN_THREADS / tpp;
+  const int max_slabs = clampi(d->hw / plc, 1, GN_MAX_SLABS);
+  a.nslab_stats = clampi(2048 / d->n, 1, max_slabs);
+  const int nslab_apply = clampi(4096 / d->n, 1, clampi(d->hw / plc, 1, 1024));
+  hipStream_t s = (hipStream_t)stream;
+  const double bytes = (double)d->n * d->hw * C * (4.0 + 4.0 + 2.0);
+  SevaProfScope prof(3, bytes, s);
+  const size_t lds = (size_t)plc * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(GN_THREADS), lds, s, a);
+  int rc = seva_check_launch("gn_stats_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nslab_apply, d->n), dim3(GN_THREADS), 0, s, a);
+  return seva_check_launch("gn_apply_kernel");
+}
+
+extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const float* beta,
+                                  void* out_f16, int64_t rows, int32_t c, float eps,
+                                  seva_stream_t stream) {
+  SEVA_REQUIRE(x && gamma && beta && out_f16, "layernorm: null pointer");
+  SEVA_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && c <= 64 * 4 * LN_MAXV,
+               "layernorm: rows=%lld c=%d unsupported", (long long)rows, c);
+  hipStream_t s = (hipStream_t)stream;
+  SevaProfScope prof(3, (double)rows * c * 6.0, s);
+  const int64_t blocks = (rows + 3) / 4;
+  SEVA_REQUIRE(blocks <= 0x7fffffff, "layernorm: too many rows");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta,
+                     (half_t*)out_f16, rows, c, eps);
+  return seva_check_launch("layernorm_kernel");
+}

@@ -1,0 +1,451 @@
+"""HIP execution engine behind `seva.model.Seva.forward` (reference seva/model.py:176-216).
+
+Packs the module's parameters once into kernel-friendly fp16/fp32 device buffers and then runs
+the UNet as a fixed sequence of C-ABI kernel launches (`seva.ops`) on PyTorch's current stream.
+All intermediate buffers come from a per-shape arena that is filled on the first call, so a
+second call performs no allocation and can be captured into a hipGraph (`ops.Graph`).
+
+Data layout in HBM: channels-last activations; fp32 residual stream
+[N][h*w][C]; every GEMM/conv A-operand is an fp16 tensor written by the producing norm /
+activation / attention kernel; weights fp16 [N_out][K] with K = (ky,kx,ci) for 3x3 convs.
+
+Exact algebraic rewrites (each checked against the oracle in tests/):
+  * cross-attention with ONE context token (the only case `do_sample` produces, reference
+    eval.py:1248 / transformer.py:222-226): softmax over one key is 1, so
+    attn2(x, ctx) == to_out(to_v(ctx)) for every query; W_out @ W_v is folded at pack time and all
+    32 such vectors are produced by one GEMM per forward.  Longer contexts take the general
+    path (`_cross_attention_general`).
+  * the skip concat (model.py:206-207) is never materialised for GroupNorm (two-source reads).
+  * `(b t) s c <-> (b s) t c` transposes of the time-mix block (transformer.py:149,154) vanish:
+    token-wise ops run in place and the temporal attention reads through strides.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from ._arch import Layout
+from ._native import SevaNativeError, require_cuda
+
+F16, F32 = torch.float16, torch.float32
+CIN_PAD = 64  # conv A-operand channel granularity (one K-tile per tap)
+
+
+# --------------------------------------------------------------------------- weight packing
+def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
+    """[cout, cin, 3, 3] -> f16 [cout, 9*cin_pad], K ordered (ky, kx, ci); extra channels zero."""
+    cout, cin = w.shape[:2]
+    cin_pad = cin_pad or cin
+    out = torch.zeros((cout, 3, 3, cin_pad), dtype=F16, device=w.device)
+    out[..., :cin] = w.permute(0, 2, 3, 1).to(F16)
+    return out.reshape(cout, 9 * cin_pad).contiguous()
+
+
+def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
+    """Reorder GEGLU projection rows (value rows 0..Nh-1, gate rows Nh..2Nh-1, reference
+    transformer.py:13-14) into groups of 64 = [32 value | 32 gate] (include/seva_hip.h)."""
+    nh = w.shape[0] // 2
+    g = nh // 32
+    wi = torch.stack([w[:nh].reshape(g, 32, -1), w[nh:].reshape(g, 32, -1)], 1).reshape(2 * nh, -1)
+    bi = torch.stack([b[:nh].reshape(g, 32), b[nh:].reshape(g, 32)], 1).reshape(2 * nh)
+    return wi.contiguous(), bi.contiguous()
+
+
+class _Arena:
+    """Shape-keyed buffer cache: the second forward of a shape allocates nothing."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: dict = {}
+
+    def get(self, name: str, shape, dtype) -> torch.Tensor:
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(key[1], dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class SevaEngine:
+    def __init__(self, model):
+        params = [p for p in model.parameters()]
+        if not params or params[0].device.type != "cuda":
+            raise SevaNativeError(
+                "Seva.forward runs only on an AMD GPU: move the module to a cuda device first "
+                "(there is no CPU fallback)."
+            )
+        from . import _native
+
+        _native.load()
+        self.device = params[0].device
+        self.p = model.params
+        self.layout: Layout = model._layout
+        self.arena = _Arena(self.device)
+        self._pack(model)
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self, model) -> None:
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        dev = self.device
+        W: dict[str, torch.Tensor] = {}
+
+        def f16(k):
+            return sd[k].to(device=dev, dtype=F16).contiguous()
+
+        def f32(k):
+            return sd[k].to(device=dev, dtype=F32).contiguous()
+
+        mc = self.p.model_channels
+        half = mc // 2
+        W["freqs"] = torch.exp(
+            -math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half
+        ).to(dev)
+        for k in ("time_embed.0", "time_embed.2"):
+            W[k + ".w"], W[k + ".b"] = f16(k + ".weight"), f32(k + ".bias")
+
+        emb_w, emb_b, ctx_w, ctx_b = [], [], [], []
+        self.emb_off: dict[str, int] = {}
+        self.ctx_off: dict[str, int] = {}
+        emb_total = ctx_total = 0
+
+        def pack_attn_self(pfx):
+            W[pfx + ".qkv"] = torch.cat(
+                [f16(pfx + ".to_q.weight"), f16(pfx + ".to_k.weight"), f16(pfx + ".to_v.weight")], 0
+            ).contiguous()
+            W[pfx + ".out.w"], W[pfx + ".out.b"] = f16(pfx + ".to_out.0.weight"), f32(pfx + ".to_out.0.bias")
+
+        def pack_attn_cross(pfx):
+            nonlocal ctx_total
+            wv, wo = f32(pfx + ".to_v.weight"), f32(pfx + ".to_out.0.weight")
+            ctx_w.append((wo.double() @ wv.double()).to(F16))  # folded W_out @ W_v  [C, ctx]
+            ctx_b.append(f32(pfx + ".to_out.0.bias"))
+            self.ctx_off[pfx] = ctx_total
+            ctx_total += wo.shape[0]
+            # general path (context length > 1)
+            W[pfx + ".q"] = f16(pfx + ".to_q.weight")
+            W[pfx + ".kv"] = torch.cat([f16(pfx + ".to_k.weight"), f16(pfx + ".to_v.weight")], 0).contiguous()
+            W[pfx + ".out.w"], W[pfx + ".out.b"] = f16(pfx + ".to_out.0.weight"), f32(pfx + ".to_out.0.bias")
+
+        def pack_ff(pfx):
+            wi, bi = interleave_geglu(f16(pfx + ".net.0.proj.weight"), f32(pfx + ".net.0.proj.bias"))
+            W[pfx + ".w1"], W[pfx + ".b1"] = wi, bi
+            W[pfx + ".w2"], W[pfx + ".b2"] = f16(pfx + ".net.2.weight"), f32(pfx + ".net.2.bias")
+
+        def pack_ln(pfx):
+            W[pfx + ".g"], W[pfx + ".b"] = f32(pfx + ".weight"), f32(pfx + ".bias")
+
+        for spec in self.layout.all_specs():
+            pfx = spec.prefix
+            if spec.kind == "conv":
+                W[pfx + ".w"] = pack_conv3x3(f32(pfx + ".weight"), CIN_PAD * ((spec.cin + CIN_PAD - 1) // CIN_PAD))
+                W[pfx + ".b"] = f32(pfx + ".bias")
+            elif spec.kind == "res":
+                assert spec.cin % 64 == 0 and spec.cout % 64 == 0, "channel counts must be multiples of 64"
+                pack_ln(pfx + ".in_layers.0")
+                pack_ln(pfx + ".out_layers.0")
+                W[pfx + ".conv1.w"] = pack_conv3x3(f32(pfx + ".in_layers.2.weight"))
+                W[pfx + ".conv1.b"] = f32(pfx + ".in_layers.2.bias")
+                W[pfx + ".conv2.w"] = pack_conv3x3(f32(pfx + ".out_layers.3.weight"))
+                W[pfx + ".conv2.b"] = f32(pfx + ".out_layers.3.bias")
+                W[pfx + ".dense.w"] = f32(pfx + ".dense_emb_layers.0.weight").reshape(2 * spec.cin, -1).contiguous()
+                W[pfx + ".dense.b"] = f32(pfx + ".dense_emb_layers.0.bias")
+                emb_w.append(f16(pfx + ".emb_layers.1.weight"))
+                emb_b.append(f32(pfx + ".emb_layers.1.bias"))
+                self.emb_off[pfx] = emb_total
+                emb_total += spec.cout
+                if spec.cin != spec.cout:
+                    W[pfx + ".skip.w"] = f16(pfx + ".skip_connection.weight").reshape(spec.cout, spec.cin).contiguous()
+                    W[pfx + ".skip.b"] = f32(pfx + ".skip_connection.bias")
+            elif spec.kind == "mvt":
+                pack_ln(pfx + ".norm")
+                W[pfx + ".proj_in.w"], W[pfx + ".proj_in.b"] = f16(pfx + ".proj_in.weight"), f32(pfx + ".proj_in.bias")
+                W[pfx + ".proj_out.w"], W[pfx + ".proj_out.b"] = f16(pfx + ".proj_out.weight"), f32(pfx + ".proj_out.bias")
+                for i in range(spec.depth):
+                    b = f"{pfx}.transformer_blocks.{i}"
+                    pack_attn_self(b + ".attn1")
+                    pack_attn_cross(b + ".attn2")
+                    pack_ff(b + ".ff")
+                    for n in ("norm1", "norm2", "norm3"):
+                        pack_ln(f"{b}.{n}")
+                    m = f"{pfx}.time_mix_blocks.{i}"
+                    pack_attn_self(m + ".attn1")
+                    pack_attn_cross(m + ".attn2")
+                    pack_ff(m + ".ff_in")
+                    pack_ff(m + ".ff")
+                    for n in ("norm_in", "norm1", "norm2", "norm3"):
+                        pack_ln(f"{m}.{n}")
+            elif spec.kind == "down":
+                W[pfx + ".w"], W[pfx + ".b"] = pack_conv3x3(f32(pfx + ".op.weight")), f32(pfx + ".op.bias")
+            elif spec.kind == "up":
+                W[pfx + ".w"], W[pfx + ".b"] = pack_conv3x3(f32(pfx + ".conv.weight")), f32(pfx + ".conv.bias")
+        pack_ln("out.0")
+        W["out.2.w"], W["out.2.b"] = pack_conv3x3(f32("out.2.weight")), f32("out.2.bias")
+        W["emb_all.w"], W["emb_all.b"] = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
+        W["ctx_all.w"], W["ctx_all.b"] = torch.cat(ctx_w, 0).contiguous(), torch.cat(ctx_b, 0).contiguous()
+        self.emb_total, self.ctx_total = emb_total, ctx_total
+        self.W = W
+
+    # ------------------------------------------------------------------ helpers
+    def _buf(self, name, shape, dtype):
+        return self.arena.get(name, shape, dtype)
+
+    def _ln(self, x, pfx, rows, c):
+        out = self._buf("ln16", (rows, c), F16)
+        ops.layernorm(x, self.W[pfx + ".g"], self.W[pfx + ".b"], out)
+        return out
+
+    def _ff(self, x32, ln_pfx, ff_pfx, rows, c, *, residual, out_f32=None, out_f16=None):
+        """GEGLU feed-forward on LayerNorm(x32): reference transformer.py:18-34."""
+        a = self._ln(x32, ln_pfx, rows, c)
+        hidden = self._buf("ffh", (rows, 4 * c), F16)
+        ops.gemm(a, self.W[ff_pfx + ".w1"], bias=self.W[ff_pfx + ".b1"], out_f16=hidden, geglu=True)
+        ops.gemm(hidden, self.W[ff_pfx + ".w2"], bias=self.W[ff_pfx + ".b2"], residual=residual,
+                 out_f32=out_f32, out_f16=out_f16)
+
+    # ------------------------------------------------------------------ blocks
+    def _resblock(self, spec, x1, x2, n, h, w, dense, emb_all):
+        """ResBlock.forward, reference layers.py:120-139.  x1 (‖ x2) fp32 [n, hw, c]."""
+        W, pfx, hw = self.W, spec.prefix, h * w
+        cin, cout = spec.cin, spec.cout
+        a16 = self._buf("gn16", (n, hw, cin), F16)
+        ops.groupnorm(x1, x2, W[pfx + ".in_layers.0.g"], W[pfx + ".in_layers.0.b"], a16, self.gn_ws,
+                      eps=1e-5, silu=True, dense=dense, dense_w=W[pfx + ".dense.w"], dense_b=W[pfx + ".dense.b"])
+        hmid = self._buf("res_mid", (n, hw, cout), F32)
+        off = self.emb_off[pfx]
+        ops.conv3x3(a16.view(n, h, w, cin), W[pfx + ".conv1.w"], bias=W[pfx + ".conv1.b"],
+                    row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
+        b16 = self._buf("gn16", (n, hw, cout), F16)
+        ops.groupnorm(hmid, None, W[pfx + ".out_layers.0.g"], W[pfx + ".out_layers.0.b"], b16, self.gn_ws,
+                      eps=1e-5, silu=True)
+        if cin != cout:
+            xs16 = self._buf("skip16", (n * hw, cin), F16)
+            ops.cast_concat_f16(x1, x2, xs16)
+            res = self._buf("skip32", (n * hw, cout), F32)
+            ops.gemm(xs16, W[pfx + ".skip.w"], bias=W[pfx + ".skip.b"], out_f32=res)
+        else:
+            assert x2 is None
+            res = x1
+        out = self._buf("out:" + pfx, (n, hw, cout), F32)
+        ops.conv3x3(b16.view(n, h, w, cout), W[pfx + ".conv2.w"], bias=W[pfx + ".conv2.b"],
+                    residual=res, out_f32=out)
+        return out
+
+    def _self_attention(self, x32, ln_pfx, at_pfx, rows, c, heads, *, regime, n, hw, T, residual,
+                        row_add, rpg, ldra, out_f32):
+        """Attention.forward (self), reference transformer.py:59-74, + residual (+ folded attn2)."""
+        W = self.W
+        a = self._ln(x32, ln_pfx, rows, c)
+        qkv = self._buf("qkv", (rows, 3 * c), F16)
+        ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv)
+        att = self._buf("att", (rows, c), F16)
+        q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+        c3 = 3 * c
+        if regime == "frame":  # batch = frame, tokens = pixels
+            ops.attention(q, k, v, att, nb0=n, nb1=1, heads=heads, lq=hw, lk=hw,
+                          q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * c, 0, c))
+        elif regime == "joint":  # batch = scene, tokens = (frame, pixel)
+            ops.attention(q, k, v, att, nb0=n // T, nb1=1, heads=heads, lq=T * hw, lk=T * hw,
+                          q_strides=(T * hw * c3, 0, c3), k_strides=(T * hw * c3, 0, c3),
+                          o_strides=(T * hw * c, 0, c))
+        else:  # temporal: batch = (scene, pixel), tokens = frames, read through strides
+            ops.attention(q, k, v, att, nb0=n // T, nb1=hw, heads=heads, lq=T, lk=T,
+                          q_strides=(T * hw * c3, c3, hw * c3), k_strides=(T * hw * c3, c3, hw * c3),
+                          o_strides=(T * hw * c, c, hw * c))
+        ops.gemm(att, W[at_pfx + ".out.w"], bias=W[at_pfx + ".out.b"], residual=residual,
+                 row_add=row_add, rows_per_group=rpg, ld_row_add=ldra, out_f32=out_f32)
+
+    def _cross_attention_general(self, x32, ln_pfx, at_pfx, rows, c, heads, ctx16, lc, *, nb0, nb1,
+                                 lq, q_strides, o_strides, ctx_batch_stride, out_f32):
+        """Attention.forward with a context of length > 1 (reference transformer.py:59-74)."""
+        W = self.W
+        a = self._ln(x32, ln_pfx, rows, c)
+        q = self._buf("xq", (rows, c), F16)
+        ops.gemm(a, W[at_pfx + ".q"], out_f16=q)
+        kv = self._buf("xkv", (ctx16.shape[0], 2 * c), F16)
+        ops.gemm(ctx16, W[at_pfx + ".kv"], out_f16=kv)
+        att = self._buf("att", (rows, c), F16)
+        ops.attention(q, kv[:, :c], kv[:, c:], att, nb0=nb0, nb1=nb1, heads=heads, lq=lq, lk=lc,
+                      q_strides=q_strides, k_strides=(ctx_batch_stride * 2 * c, 0, 2 * c),
+                      o_strides=o_strides)
+        ops.gemm(att, W[at_pfx + ".out.w"], bias=W[at_pfx + ".out.b"], residual=x32, out_f32=out_f32)
+
+    def _transformer(self, spec, x, n, h, w, T, ctxvec, ctx16, lc):
+        """MultiviewTransformer.forward, reference transformer.py:215-247."""
+        W, pfx, hw, c, heads = self.W, spec.prefix, h * w, spec.channels, spec.heads
+        rows = n * hw
+        g16 = self._buf("gn16", (n, hw, c), F16)
+        ops.groupnorm(x, None, W[pfx + ".norm.g"], W[pfx + ".norm.b"], g16, self.gn_ws, eps=1e-6, silu=False)
+        cur = self._buf("t_h", (rows, c), F32)
+        ops.gemm(g16.view(rows, c), W[pfx + ".proj_in.w"], bias=W[pfx + ".proj_in.b"], out_f32=cur)
+        collapse = lc == 1
+        ldra_frame, ldra_scene = self.ctx_total, T * self.ctx_total
+        last16 = None
+        for i in range(spec.depth):
+            b = f"{pfx}.transformer_blocks.{i}"
+            m = f"{pfx}.time_mix_blocks.{i}"
+            regime = "joint" if spec.joint else "frame"
+            # x = attn1(norm1 x) + x ; x = attn2(norm2 x, ctx) + x
+            h1 = self._buf("t_h1", (rows, c), F32)
+            if collapse:
+                ra = ctxvec[:, self.ctx_off[b + ".attn2"]:]
+                rpg, ldra = (T * hw, ldra_scene) if spec.joint else (hw, ldra_frame)
+                self._self_attention(cur, b + ".norm1", b + ".attn1", rows, c, heads, regime=regime, n=n,
+                                     hw=hw, T=T, residual=cur, row_add=ra, rpg=rpg, ldra=ldra, out_f32=h1)
+            else:
+                h0 = self._buf("t_h0", (rows, c), F32)
+                self._self_attention(cur, b + ".norm1", b + ".attn1", rows, c, heads, regime=regime, n=n,
+                                     hw=hw, T=T, residual=cur, row_add=None, rpg=0, ldra=0, out_f32=h0)
+                if spec.joint:  # context[::T], one per scene
+                    self._cross_attention_general(
+                        h0, b + ".norm2", b + ".attn2", rows, c, heads, ctx16, lc, nb0=n // T, nb1=1,
+                        lq=T * hw, q_strides=(T * hw * c, 0, c), o_strides=(T * hw * c, 0, c),
+                        ctx_batch_stride=T * lc, out_f32=h1)
+                else:
+                    self._cross_attention_general(
+                        h0, b + ".norm2", b + ".attn2", rows, c, heads, ctx16, lc, nb0=n, nb1=1, lq=hw,
+                        q_strides=(hw * c, 0, c), o_strides=(hw * c, 0, c), ctx_batch_stride=lc, out_f32=h1)
+            # x = ff(norm3 x) + x
+            h2 = self._buf("t_h2", (rows, c), F32)
+            self._ff(h1, b + ".norm3", b + ".ff", rows, c, residual=h1, out_f32=h2)
+            # ---- time-mix block on x_spatial = h2 (transformer.py:145-155) ----
+            m1 = self._buf("t_m1", (rows, c), F32)
+            self._ff(h2, m + ".norm_in", m + ".ff_in", rows, c, residual=h2, out_f32=m1)
+            m2 = self._buf("t_m2", (rows, c), F32)
+            if collapse:
+                ra = ctxvec[:, self.ctx_off[m + ".attn2"]:]
+                self._self_attention(m1, m + ".norm1", m + ".attn1", rows, c, heads, regime="temporal", n=n,
+                                     hw=hw, T=T, residual=m1, row_add=ra, rpg=T * hw, ldra=ldra_scene, out_f32=m2)
+            else:
+                m0 = self._buf("t_m0", (rows, c), F32)
+                self._self_attention(m1, m + ".norm1", m + ".attn1", rows, c, heads, regime="temporal", n=n,
+                                     hw=hw, T=T, residual=m1, row_add=None, rpg=0, ldra=0, out_f32=m0)
+                self._cross_attention_general(
+                    m0, m + ".norm2", m + ".attn2", rows, c, heads, ctx16, lc, nb0=n // T, nb1=hw, lq=T,
+                    q_strides=(T * hw * c, c, hw * c), o_strides=(T * hw * c, c, hw * c),
+                    ctx_batch_stride=T * lc, out_f32=m2)
+            # x = x_spatial + ff(norm3 x_mix)   (time-mix ff has no residual; SkipConnect adds)
+            final = i == spec.depth - 1
+            nxt = None if final else self._buf("t_h", (rows, c), F32)
+            last16 = self._buf("t_h16", (rows, c), F16)
+            self._ff(m2, m + ".norm3", m + ".ff", rows, c, residual=h2, out_f32=nxt, out_f16=last16)
+            cur = nxt
+        out = self._buf("out:" + pfx, (n, hw, c), F32)
+        ops.gemm(last16, W[pfx + ".proj_out.w"], bias=W[pfx + ".proj_out.b"], residual=x.view(rows, c),
+                 out_f32=out.view(rows, c))
+        return out
+
+    def _resample(self, spec, x, n, h, w):
+        """Downsample (layers.py:49-58) / Upsample (layers.py:35-46)."""
+        c = spec.channels
+        x16 = self._buf("rs16", (n, h, w, c), F16)
+        ops.cast_concat_f16(x, None, x16)
+        if spec.kind == "down":
+            oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            out = self._buf("out:" + spec.prefix, (n, oh * ow, c), F32)
+            ops.conv3x3(x16, self.W[spec.prefix + ".w"], stride=2, bias=self.W[spec.prefix + ".b"], out_f32=out)
+        else:
+            oh, ow = 2 * h, 2 * w
+            out = self._buf("out:" + spec.prefix, (n, oh * ow, c), F32)
+            ops.conv3x3(x16, self.W[spec.prefix + ".w"], upsample=True, bias=self.W[spec.prefix + ".b"], out_f32=out)
+        return out, oh, ow
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, concat, t, y, dense_y, num_frames, out=None):
+        """x: [n, c, h, w] f32 (‖ concat on channels), t: [n] int64 sigma indices, y: [n, L, ctx],
+        dense_y: [n, 6, hd, wd].  Returns [n, out_channels, h, w] f32."""
+        require_cuda(x, t, y, dense_y)
+        W, p, lay = self.W, self.p, self.layout
+        x = x.to(F32).contiguous()
+        concat = None if concat is None or concat.numel() == 0 else concat.to(F32).contiguous()
+        dense_y = dense_y.to(F32).contiguous()
+        n, cx, h, w = x.shape
+        T = int(num_frames)
+        cin = cx + (concat.shape[1] if concat is not None else 0)
+        if cin != p.in_channels:
+            raise ValueError(f"expected {p.in_channels} input channels, got {cin}")
+        if n % T:
+            raise ValueError(f"batch {n} is not a multiple of num_frames {T}")
+        assert y.ndim == 3
+        lc = y.shape[1]
+        t = t.to(torch.int64).contiguous()
+        self.gn_ws = self._buf("gn_ws", (n * 64 * 32 * 2,), F32)
+
+        # --- prologue: timestep embedding MLP, all ResBlock emb projections, folded cross-attn ---
+        mc, ed = p.model_channels, lay.time_embed_dim
+        te16 = self._buf("te16", (n, mc), F16)
+        ops.timestep_embedding_f16(t, W["freqs"], te16)
+        e1 = self._buf("te_h", (n, ed), F32)
+        ops.gemm(te16, W["time_embed.0.w"], bias=W["time_embed.0.b"], out_f32=e1)
+        e1a = self._buf("te_h16", (n, ed), F16)
+        ops.silu_f16(e1, e1a)
+        emb = self._buf("emb", (n, ed), F32)
+        ops.gemm(e1a, W["time_embed.2.w"], bias=W["time_embed.2.b"], out_f32=emb)
+        emb_a = self._buf("emb16", (n, ed), F16)
+        ops.silu_f16(emb, emb_a)
+        emb_all = self._buf("emb_all", (n, self.emb_total), F32)
+        ops.gemm(emb_a, W["emb_all.w"], bias=W["emb_all.b"], out_f32=emb_all)
+        ctx16 = self._buf("ctx16", (n * lc, y.shape[2]), F16)
+        ops.cast_concat_f16(y.to(F32).contiguous().view(n * lc, -1), None, ctx16)
+        ctxvec = None
+        if lc == 1:
+            ctxvec = self._buf("ctxvec", (n, self.ctx_total), F32)
+            ops.gemm(ctx16, W["ctx_all.w"], bias=W["ctx_all.b"], out_f32=ctxvec)
+
+        dense_cache: dict = {}
+
+        def dense_at(hh, ww):
+            key = (hh, ww)
+            if key not in dense_cache:
+                d = self._buf("dense", (n, hh * ww, dense_y.shape[1]), F32)
+                ops.bilinear_to_nhwc(dense_y, d, hh, ww)
+                dense_cache[key] = d
+            return dense_cache[key]
+
+        # --- stem ---
+        stem = lay.input_blocks[0][0]
+        cpad = CIN_PAD * ((cin + CIN_PAD - 1) // CIN_PAD)
+        x16 = self._buf("x16", (n, h, w, cpad), F16)
+        ops.nchw_to_nhwc_f16(x, concat, x16)
+        cur = self._buf("out:" + stem.prefix, (n, h * w, stem.cout), F32)
+        ops.conv3x3(x16, W[stem.prefix + ".w"], bias=W[stem.prefix + ".b"], out_f32=cur)
+        ch, cw = h, w
+        hs = [(cur, ch, cw)]
+
+        def run(block, cur, x2, ch, cw):
+            for spec in block:
+                if spec.kind == "res":
+                    cur = self._resblock(spec, cur, x2, n, ch, cw, dense_at(ch, cw), emb_all)
+                    x2 = None
+                elif spec.kind == "mvt":
+                    cur = self._transformer(spec, cur, n, ch, cw, T, ctxvec, ctx16, lc)
+                else:
+                    cur, ch, cw = self._resample(spec, cur, n, ch, cw)
+            return cur, ch, cw
+
+        for block in lay.input_blocks[1:]:
+            cur, ch, cw = run(block, cur, None, ch, cw)
+            hs.append((cur, ch, cw))
+        cur, ch, cw = run(lay.middle, cur, None, ch, cw)
+        for block in lay.output_blocks:
+            skip, sh, sw = hs.pop()
+            assert (sh, sw) == (ch, cw)
+            cur, ch, cw = run(block, cur, skip, ch, cw)
+
+        # --- head: GroupNorm + SiLU + conv3x3 (model.py:170-174) ---
+        cfin = lay.final_channels
+        g16 = self._buf("gn16", (n, ch * cw, cfin), F16)
+        ops.groupnorm(cur, None, W["out.0.g"], W["out.0.b"], g16, self.gn_ws, eps=1e-5, silu=True)
+        o_nhwc = self._buf("head", (n, ch * cw, p.out_channels), F32)
+        ops.conv3x3(g16.view(n, ch, cw, cfin), W["out.2.w"], bias=W["out.2.b"], out_f32=o_nhwc)
+        if out is None:
+            out = torch.empty((n, p.out_channels, ch, cw), dtype=F32, device=self.device)
+        ops.nhwc_to_nchw_f32(o_nhwc, out)
+        return out

@@ -1,0 +1,146 @@
+"""ctypes binding of libseva_hip.so (C-ABI declared in include/seva_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved the
+import of the HIP-backed operators fails loudly (`SevaNativeError`).  Nothing in this package
+computes the hot path with PyTorch ops.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
+ABI_VERSION = 1
+PROF_CLASSES = 5
+PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
+
+
+class SevaNativeError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("row_add", c_void_p),
+        ("residual", c_void_p), ("out_f32", c_void_p), ("out_f16", c_void_p),
+        ("M", c_int64), ("N", c_int64), ("K", c_int64),
+        ("lda", c_int64), ("ldr", c_int64), ("ldo32", c_int64), ("ldo16", c_int64),
+        ("rows_per_group", c_int64), ("ld_row_add", c_int64),
+        ("mode", c_int32), ("epilogue", c_int32),
+        ("n", c_int32), ("ih", c_int32), ("iw", c_int32), ("cin", c_int32),
+        ("oh", c_int32), ("ow", c_int32), ("stride", c_int32), ("upsample", c_int32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p),
+        ("q_sb0", c_int64), ("q_sb1", c_int64), ("q_sl", c_int64),
+        ("k_sb0", c_int64), ("k_sb1", c_int64), ("k_sl", c_int64),
+        ("o_sb0", c_int64), ("o_sb1", c_int64), ("o_sl", c_int64),
+        ("nb0", c_int32), ("nb1", c_int32), ("heads", c_int32),
+        ("lq", c_int32), ("lk", c_int32), ("scale", c_float),
+    ]
+
+
+class GroupNormDesc(C.Structure):
+    _fields_ = [
+        ("x1", c_void_p), ("x2", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+        ("dense", c_void_p), ("dense_w", c_void_p), ("dense_b", c_void_p),
+        ("out_f16", c_void_p), ("workspace", c_void_p),
+        ("n", c_int32), ("hw", c_int32), ("c1", c_int32), ("c2", c_int32),
+        ("groups", c_int32), ("dense_c", c_int32), ("silu", c_int32), ("eps", c_float),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/seva_hip.h
+SYMBOLS = {
+    "seva_last_error": (c_char_p, []),
+    "seva_abi_version": (c_int, []),
+    "seva_target_arch": (c_char_p, []),
+    "seva_gemm_f16": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "seva_attention_f16": (c_int, [POINTER(AttnDesc), c_void_p]),
+    "seva_groupnorm_f16": (c_int, [POINTER(GroupNormDesc), c_void_p]),
+    "seva_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "seva_nchw_to_nhwc_f16": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "seva_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "seva_cast_concat_f16": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+    "seva_bilinear_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "seva_timestep_embedding_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "seva_silu_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "seva_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "seva_replace_blend_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "seva_denoiser_combine_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_add_noise_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_cfg_euler_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_cfg_combine_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_euler_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_to_d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_scale_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_graph_begin": (c_int, [c_void_p]),
+    "seva_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "seva_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "seva_graph_destroy": (c_int, [c_void_p]),
+    "seva_prof_enable": (c_int, [c_int]),
+    "seva_prof_collect": (c_int, [POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libseva_hip.so and bind every symbol; raises SevaNativeError on any problem."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SevaNativeError(
+            f"{LIB_PATH} not found: build it with `make -C stable-virtual-camera_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise SevaNativeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SevaNativeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.seva_abi_version() != ABI_VERSION:
+        raise SevaNativeError(
+            f"ABI mismatch: library {lib.seva_abi_version()} vs binding {ABI_VERSION}"
+        )
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().seva_last_error().decode("utf-8", "replace")
+        raise SevaNativeError(f"{what or 'seva native call'} failed (rc={rc}): {msg}")
+
+
+def stream_ptr(device=None) -> int:
+    """Raw hipStream_t of PyTorch's current stream (kernels launch on it)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SevaNativeError(
+                "seva HIP operators need tensors on an AMD GPU (cuda device); "
+                "there is no CPU fallback path."
+            )

@@ -1,0 +1,322 @@
+"""Tensor-level wrappers over the C-ABI operators of libseva_hip.so.
+
+Every function enqueues HIP kernels on PyTorch's current stream through raw device pointers;
+PyTorch is used for memory and streams only.  Outputs are caller-provided (graph-capture
+friendly: no allocation happens here unless `out=None`).  Layouts follow include/seva_hip.h:
+channels-last activations, f16 GEMM operands, f32 residual stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as nv
+from ._native import AttnDesc, GemmDesc, GroupNormDesc, check, ptr, require_cuda, stream_ptr
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _lib():
+    return nv.load()
+
+
+def gemm(
+    a: torch.Tensor,
+    w: torch.Tensor,
+    *,
+    bias: torch.Tensor | None = None,
+    row_add: torch.Tensor | None = None,
+    rows_per_group: int = 0,
+    ld_row_add: int = 0,
+    residual: torch.Tensor | None = None,
+    out_f32: torch.Tensor | None = None,
+    out_f16: torch.Tensor | None = None,
+    geglu: bool = False,
+) -> None:
+    """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16)."""
+    require_cuda(a, w)
+    assert a.dtype == F16 and w.dtype == F16 and a.dim() == 2 and w.dim() == 2
+    M, K = a.shape
+    N = w.shape[0]
+    d = GemmDesc()
+    d.a, d.w = a.data_ptr(), w.data_ptr()
+    d.bias, d.row_add, d.residual = ptr(bias), ptr(row_add), ptr(residual)
+    d.out_f32, d.out_f16 = ptr(out_f32), ptr(out_f16)
+    d.M, d.N, d.K = M, N, K
+    d.lda = a.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.ldo32 = out_f32.stride(0) if out_f32 is not None else 0
+    d.ldo16 = out_f16.stride(0) if out_f16 is not None else 0
+    d.rows_per_group, d.ld_row_add = rows_per_group, ld_row_add
+    d.mode, d.epilogue = 0, 1 if geglu else 0
+    check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(a.device)), "seva_gemm_f16")
+
+
+def conv3x3(
+    x: torch.Tensor,
+    w: torch.Tensor,
+    *,
+    stride: int = 1,
+    upsample: bool = False,
+    bias: torch.Tensor | None = None,
+    row_add: torch.Tensor | None = None,
+    rows_per_group: int = 0,
+    ld_row_add: int = 0,
+    residual: torch.Tensor | None = None,
+    out_f32: torch.Tensor | None = None,
+    out_f16: torch.Tensor | None = None,
+) -> None:
+    """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16."""
+    require_cuda(x, w)
+    assert x.dtype == F16 and w.dtype == F16 and x.dim() == 4 and x.is_contiguous()
+    n, ih, iw, cin = x.shape
+    eh, ew = (2 * ih, 2 * iw) if upsample else (ih, iw)
+    oh, ow = (eh - 1) // stride + 1, (ew - 1) // stride + 1
+    d = GemmDesc()
+    d.a, d.w = x.data_ptr(), w.data_ptr()
+    d.bias, d.row_add, d.residual = ptr(bias), ptr(row_add), ptr(residual)
+    d.out_f32, d.out_f16 = ptr(out_f32), ptr(out_f16)
+    d.M, d.N, d.K = n * oh * ow, w.shape[0], 9 * cin
+    d.lda = cin
+    d.ldr = residual.stride(-2) if residual is not None else 0
+    d.ldo32 = out_f32.stride(-2) if out_f32 is not None else 0
+    d.ldo16 = out_f16.stride(-2) if out_f16 is not None else 0
+    d.rows_per_group, d.ld_row_add = rows_per_group, ld_row_add
+    d.mode, d.epilogue = 1, 0
+    d.n, d.ih, d.iw, d.cin, d.oh, d.ow = n, ih, iw, cin, oh, ow
+    d.stride, d.upsample = stride, 1 if upsample else 0
+    check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(x.device)), "seva_gemm_f16(conv)")
+
+
+def attention(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    out: torch.Tensor,
+    *,
+    nb0: int,
+    nb1: int,
+    heads: int,
+    lq: int,
+    lk: int,
+    q_strides: tuple[int, int, int],
+    k_strides: tuple[int, int, int],
+    o_strides: tuple[int, int, int],
+    scale: float = 0.125,
+) -> None:
+    """softmax(q k^T * scale) v per (batch, head), head dim 64 (seva_attention_f16).
+
+    q/k/v/out are f16 tensors (any views); strides are (batch-outer, batch-inner, token) in
+    elements relative to the tensors' data pointers; head h sits at element offset 64*h."""
+    require_cuda(q, k, v, out)
+    d = AttnDesc()
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.q_sb0, d.q_sb1, d.q_sl = q_strides
+    d.k_sb0, d.k_sb1, d.k_sl = k_strides
+    d.o_sb0, d.o_sb1, d.o_sl = o_strides
+    d.nb0, d.nb1, d.heads, d.lq, d.lk, d.scale = nb0, nb1, heads, lq, lk, scale
+    check(_lib().seva_attention_f16(C.byref(d), stream_ptr(q.device)), "seva_attention_f16")
+
+
+def groupnorm_workspace(n: int, device) -> torch.Tensor:
+    return torch.empty(n * 64 * 32 * 2, dtype=F32, device=device)
+
+
+def groupnorm(
+    x1: torch.Tensor,
+    x2: torch.Tensor | None,
+    gamma: torch.Tensor,
+    beta: torch.Tensor,
+    out_f16: torch.Tensor,
+    workspace: torch.Tensor,
+    *,
+    groups: int = 32,
+    eps: float = 1e-5,
+    silu: bool = False,
+    dense: torch.Tensor | None = None,
+    dense_w: torch.Tensor | None = None,
+    dense_b: torch.Tensor | None = None,
+) -> None:
+    """GroupNorm(+SiLU)(+Pluecker modulation) of cat(x1, x2) -> f16; x: [n, hw, c] f32."""
+    require_cuda(x1, out_f16)
+    n, hw, c1 = x1.shape
+    c2 = x2.shape[2] if x2 is not None else 0
+    d = GroupNormDesc()
+    d.x1, d.x2, d.gamma, d.beta = x1.data_ptr(), ptr(x2), gamma.data_ptr(), beta.data_ptr()
+    d.dense, d.dense_w, d.dense_b = ptr(dense), ptr(dense_w), ptr(dense_b)
+    d.out_f16, d.workspace = out_f16.data_ptr(), workspace.data_ptr()
+    d.n, d.hw, d.c1, d.c2, d.groups = n, hw, c1, c2, groups
+    d.dense_c = dense.shape[-1] if dense is not None else 0
+    d.silu, d.eps = 1 if silu else 0, eps
+    assert workspace.numel() >= n * 64 * groups * 2
+    check(_lib().seva_groupnorm_f16(C.byref(d), stream_ptr(x1.device)), "seva_groupnorm_f16")
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_f16: torch.Tensor,
+              eps: float = 1e-5) -> None:
+    require_cuda(x, out_f16)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    check(_lib().seva_layernorm_f16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                    out_f16.data_ptr(), rows, c, eps, stream_ptr(x.device)),
+          "seva_layernorm_f16")
+
+
+def nchw_to_nhwc_f16(x1: torch.Tensor, x2: torch.Tensor | None, out_f16: torch.Tensor,
+                     scale: torch.Tensor | None = None) -> None:
+    require_cuda(x1, out_f16)
+    n, c1 = x1.shape[:2]
+    hw = x1.numel() // (n * c1)
+    c2 = x2.shape[1] if x2 is not None else 0
+    check(_lib().seva_nchw_to_nhwc_f16(x1.data_ptr(), c1, ptr(x2), c2, ptr(scale),
+                                       out_f16.data_ptr(), n, hw, out_f16.shape[-1],
+                                       stream_ptr(x1.device)), "seva_nchw_to_nhwc_f16")
+
+
+def nhwc_to_nchw_f32(x: torch.Tensor, out: torch.Tensor) -> None:
+    """x: [n, hw, ld] f32 (first c channels used) -> out [n, c, h, w] f32."""
+    require_cuda(x, out)
+    n, c = out.shape[:2]
+    hw = out.numel() // (n * c)
+    check(_lib().seva_nhwc_to_nchw_f32(x.data_ptr(), x.stride(-2), out.data_ptr(), n, c, hw,
+                                       stream_ptr(x.device)), "seva_nhwc_to_nchw_f32")
+
+
+def cast_concat_f16(x1: torch.Tensor, x2: torch.Tensor | None, out_f16: torch.Tensor) -> None:
+    require_cuda(x1, out_f16)
+    c1 = x1.shape[-1]
+    rows = x1.numel() // c1
+    c2 = x2.shape[-1] if x2 is not None else 0
+    check(_lib().seva_cast_concat_f16(x1.data_ptr(), c1, ptr(x2), c2, out_f16.data_ptr(), rows,
+                                      stream_ptr(x1.device)), "seva_cast_concat_f16")
+
+
+def bilinear_to_nhwc(src: torch.Tensor, out: torch.Tensor, oh: int, ow: int) -> None:
+    require_cuda(src, out)
+    n, c, sh, sw = src.shape
+    check(_lib().seva_bilinear_to_nhwc_f32(src.data_ptr(), out.data_ptr(), n, c, sh, sw, oh, ow,
+                                           stream_ptr(src.device)), "seva_bilinear_to_nhwc_f32")
+
+
+def timestep_embedding_f16(t: torch.Tensor, freqs: torch.Tensor, out_f16: torch.Tensor) -> None:
+    require_cuda(t, out_f16)
+    assert t.dtype == torch.int64
+    n, dim = out_f16.shape
+    check(_lib().seva_timestep_embedding_f16(t.data_ptr(), freqs.data_ptr(), out_f16.data_ptr(),
+                                             n, dim, stream_ptr(t.device)),
+          "seva_timestep_embedding_f16")
+
+
+def silu_f16(x: torch.Tensor, out_f16: torch.Tensor) -> None:
+    require_cuda(x, out_f16)
+    check(_lib().seva_silu_f16(x.data_ptr(), out_f16.data_ptr(), x.numel(), stream_ptr(x.device)),
+          "seva_silu_f16")
+
+
+def add_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
+    require_cuda(a, b, out)
+    check(_lib().seva_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(),
+                              stream_ptr(a.device)), "seva_add_f32")
+
+
+def replace_blend(x: torch.Tensor, replace: torch.Tensor, out: torch.Tensor) -> None:
+    require_cuda(x, replace, out)
+    n, c = x.shape[:2]
+    hw = x.numel() // (n * c)
+    check(_lib().seva_replace_blend_f32(x.data_ptr(), replace.data_ptr(), out.data_ptr(), n, c, hw,
+                                        stream_ptr(x.device)), "seva_replace_blend_f32")
+
+
+def denoiser_combine(net: torch.Tensor, x: torch.Tensor, c_out: torch.Tensor, c_skip: torch.Tensor,
+                     out: torch.Tensor) -> None:
+    require_cuda(net, x, out)
+    n = x.shape[0]
+    check(_lib().seva_denoiser_combine_f32(net.data_ptr(), x.data_ptr(), c_out.data_ptr(),
+                                           c_skip.data_ptr(), out.data_ptr(), n, x.numel() // n,
+                                           stream_ptr(x.device)), "seva_denoiser_combine_f32")
+
+
+def add_noise(x: torch.Tensor, eps: torch.Tensor, noise_scale: torch.Tensor, out: torch.Tensor) -> None:
+    require_cuda(x, eps, out)
+    n = x.shape[0]
+    check(_lib().seva_add_noise_f32(x.data_ptr(), eps.data_ptr(), noise_scale.data_ptr(),
+                                    out.data_ptr(), n, x.numel() // n, stream_ptr(x.device)),
+          "seva_add_noise_f32")
+
+
+def cfg_euler(x: torch.Tensor, den2: torch.Tensor, scale: torch.Tensor, sigma_hat: torch.Tensor,
+              dt: torch.Tensor, out: torch.Tensor) -> None:
+    require_cuda(x, den2, out)
+    n = x.shape[0]
+    check(_lib().seva_cfg_euler_f32(x.data_ptr(), den2.data_ptr(), scale.data_ptr(),
+                                    sigma_hat.data_ptr(), dt.data_ptr(), out.data_ptr(), n,
+                                    x.numel() // n, stream_ptr(x.device)), "seva_cfg_euler_f32")
+
+
+def cfg_combine(den2: torch.Tensor, scale: torch.Tensor, out: torch.Tensor) -> None:
+    require_cuda(den2, scale, out)
+    n = out.shape[0]
+    check(_lib().seva_cfg_combine_f32(den2.data_ptr(), scale.data_ptr(), out.data_ptr(), n,
+                                      out.numel() // n, stream_ptr(out.device)), "seva_cfg_combine_f32")
+
+
+def euler_step(x: torch.Tensor, den: torch.Tensor, sigma_hat: torch.Tensor, dt: torch.Tensor,
+               out: torch.Tensor) -> None:
+    require_cuda(x, den, out)
+    n = x.shape[0]
+    check(_lib().seva_euler_step_f32(x.data_ptr(), den.data_ptr(), sigma_hat.data_ptr(),
+                                     dt.data_ptr(), out.data_ptr(), n, x.numel() // n,
+                                     stream_ptr(x.device)), "seva_euler_step_f32")
+
+
+def to_d(x: torch.Tensor, den: torch.Tensor, sigma: torch.Tensor, out: torch.Tensor) -> None:
+    require_cuda(x, den, out)
+    n = x.shape[0]
+    check(_lib().seva_to_d_f32(x.data_ptr(), den.data_ptr(), sigma.data_ptr(), out.data_ptr(), n,
+                               x.numel() // n, stream_ptr(x.device)), "seva_to_d_f32")
+
+
+def scale_rows(x: torch.Tensor, s: torch.Tensor, out: torch.Tensor) -> None:
+    require_cuda(x, s, out)
+    n = x.shape[0]
+    check(_lib().seva_scale_rows_f32(x.data_ptr(), s.data_ptr(), out.data_ptr(), n,
+                                     x.numel() // n, stream_ptr(x.device)), "seva_scale_rows_f32")
+
+
+# --- profiling / graphs ---------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    check(_lib().seva_prof_enable(1 if on else 0))
+
+
+def prof_collect() -> dict:
+    ms = (C.c_double * nv.PROF_CLASSES)()
+    n = (C.c_int64 * nv.PROF_CLASSES)()
+    work = (C.c_double * nv.PROF_CLASSES)()
+    check(_lib().seva_prof_collect(ms, n, work), "seva_prof_collect")
+    return {name: {"ms": ms[i], "launches": n[i], "work": work[i]}
+            for i, name in enumerate(nv.PROF_NAMES)}
+
+
+class Graph:
+    """hipGraph captured from PyTorch's current stream through the C-ABI helpers."""
+
+    def __init__(self):
+        self._exec = C.c_void_p()
+
+    def capture_begin(self, device=None) -> None:
+        check(_lib().seva_graph_begin(stream_ptr(device)), "seva_graph_begin")
+
+    def capture_end(self, device=None) -> None:
+        check(_lib().seva_graph_end(stream_ptr(device), C.byref(self._exec)), "seva_graph_end")
+
+    def launch(self, device=None) -> None:
+        check(_lib().seva_graph_launch(self._exec, stream_ptr(device)), "seva_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._exec:
+                _lib().seva_graph_destroy(self._exec)
+        except Exception:
+            pass

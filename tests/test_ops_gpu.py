@@ -1,0 +1,326 @@
+"""GPU parity of every C-ABI operator against a plain PyTorch fp32 reference of the same op.
+
+Run on the MI355X box: `python -m pytest tests -m gpu`.  GEMM-type ops are checked twice: exactly
+(small-integer data, where fp16 inputs + fp32 accumulation are exact) and on random data against
+fp32 math on the fp16-rounded operands (tolerance = accumulation-order noise only).
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from conftest import rel_l2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from seva import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+def _ints(shape, lo, hi, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float().to(dev)
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+GEMM_SHAPES = [(256, 256, 128), (128, 128, 64), (300, 320, 320), (42, 1280, 320), (1000, 4, 64),
+               (777, 960, 640), (4097, 132, 192), (64, 36, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_exact_integers(dev, M, N, K):
+    from seva import ops
+    a = _ints((M, K), -4, 4, dev, 1)
+    w = _ints((N, K), -3, 3, dev, 2)  # asymmetric, non-identity
+    bias = _ints((N,), -5, 5, dev, 3)
+    res = _ints((M, N), -9, 9, dev, 4)
+    rpg = 7
+    radd = _ints(((M + rpg - 1) // rpg, N), -3, 3, dev, 5)
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    o16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    ops.gemm(a.half(), w.half(), bias=bias, row_add=radd, rows_per_group=rpg, residual=res,
+             out_f32=o32, out_f16=o16)
+    ref = a @ w.T + bias + res + radd.repeat_interleave(rpg, 0)[:M]
+    torch.cuda.synchronize()
+    assert torch.equal(o32, ref), f"max diff {(o32 - ref).abs().max()}"
+    assert torch.equal(o16.float(), ref.half().float())
+    # no-epilogue variant, f16 output only
+    o16b = torch.empty((M, N), device=dev, dtype=torch.float16)
+    ops.gemm(a.half(), w.half(), out_f16=o16b)
+    assert torch.equal(o16b.float(), (a @ w.T).half().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (2049, 1280, 1280)])
+def test_gemm_random(dev, M, N, K):
+    from seva import ops
+    a, w = _rand((M, K), dev, 1).half(), (_rand((N, K), dev, 2) / math.sqrt(K)).half()
+    bias = _rand((N,), dev, 3)
+    o32 = torch.empty((M, N), device=dev)
+    ops.gemm(a, w, bias=bias, out_f32=o32)
+    ref = a.float() @ w.float().T + bias
+    assert rel_l2(o32, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,C", [(200, 64), (1000, 320)])
+def test_gemm_geglu(dev, M, C):
+    from seva import ops
+    from seva._engine import interleave_geglu
+    nh = 4 * C
+    a = _rand((M, C), dev, 1).half()
+    w = (_rand((2 * nh, C), dev, 2) / math.sqrt(C)).half()
+    b = _rand((2 * nh,), dev, 3, 0.1)
+    wi, bi = interleave_geglu(w, b)
+    o16 = torch.empty((M, nh), device=dev, dtype=torch.float16)
+    o32 = torch.empty((M, nh), device=dev)
+    ops.gemm(a, wi, bias=bi, out_f16=o16, out_f32=o32, geglu=True)
+    y = a.float() @ w.float().T + b
+    ref = y[:, :nh] * F.gelu(y[:, nh:])
+    assert rel_l2(o32, ref) < 3e-6
+    assert rel_l2(o16, ref) < 1e-3
+
+
+CONV_CASES = [  # n, ih, iw, cin, cout, stride, upsample
+    (2, 9, 9, 64, 64, 1, False), (3, 16, 12, 128, 96, 1, False), (2, 16, 12, 64, 64, 2, False),
+    (2, 9, 7, 64, 128, 2, False), (2, 8, 6, 64, 64, 1, True), (1, 5, 5, 192, 4, 1, False),
+    (5, 33, 31, 64, 320, 1, False),
+]
+
+
+@pytest.mark.parametrize("n,ih,iw,cin,cout,stride,up", CONV_CASES)
+def test_conv3x3(dev, n, ih, iw, cin, cout, stride, up):
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    x = _ints((n, cin, ih, iw), -3, 3, dev, 1)
+    w = _ints((cout, cin, 3, 3), -2, 2, dev, 2)
+    bias = _ints((cout,), -4, 4, dev, 3)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, bias, stride=stride, padding=1)
+    oh, ow = ref.shape[-2:]
+    temb = _ints((n, cout), -2, 2, dev, 4)
+    res = _ints((n, oh * ow, cout), -5, 5, dev, 5)
+    ref = ref + temb[:, :, None, None] + res.view(n, oh, ow, cout).permute(0, 3, 1, 2)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().half()
+    out = torch.full((n, oh * ow, cout), float("nan"), device=dev)
+    ops.conv3x3(x_nhwc, pack_conv3x3(w), stride=stride, upsample=up, bias=bias, row_add=temb,
+                rows_per_group=oh * ow, residual=res, out_f32=out)
+    got = out.view(n, oh, ow, cout).permute(0, 3, 1, 2)
+    assert torch.equal(got, ref), f"max diff {(got - ref).abs().max()}"
+
+
+def _attn_ref(q, k, v, scale):
+    att = torch.softmax((q.float() @ k.float().transpose(-1, -2)) * scale, -1)
+    return att @ v.float()
+
+
+@pytest.mark.parametrize("no_tr", ["0", "1"])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 200, 200), (2, 5, 128, 128), (1, 1, 1701, 1701),
+                                       (2, 3, 70, 5), (4, 2, 21, 21), (1, 2, 33, 64)])
+def test_attention_fused_qkv(dev, B, H, Lq, Lk, no_tr):
+    """q,k,v as column slices of a [B, L, 3C] buffer (the layout the engine uses)."""
+    from seva import ops
+    os.environ["SEVA_ATTN_NO_TR"] = no_tr
+    try:
+        C = 64 * H
+        L = max(Lq, Lk)
+        qkv = _rand((B, L, 3 * C), dev, 7).half()
+        out = torch.full((B, Lq, C), float("nan"), device=dev, dtype=torch.float16)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        ops.attention(q, k, v, out, nb0=B, nb1=1, heads=H, lq=Lq, lk=Lk,
+                      q_strides=(L * 3 * C, 0, 3 * C), k_strides=(L * 3 * C, 0, 3 * C),
+                      o_strides=(Lq * C, 0, C))
+        qh = q[:, :Lq].reshape(B, Lq, H, 64).transpose(1, 2)
+        kh = k[:, :Lk].reshape(B, Lk, H, 64).transpose(1, 2)
+        vh = v[:, :Lk].reshape(B, Lk, H, 64).transpose(1, 2)
+        ref = _attn_ref(qh, kh, vh, 0.125).transpose(1, 2).reshape(B, Lq, C)
+        err = rel_l2(out, ref)
+        assert err < 2e-3, f"rel_l2 {err}"
+    finally:
+        os.environ.pop("SEVA_ATTN_NO_TR", None)
+
+
+def test_attention_exact_uniform(dev):
+    """All-equal scores -> output is the plain mean of V (exact in fp16 for integer V)."""
+    from seva import ops
+    B, H, L = 1, 1, 64
+    q = torch.zeros((B, L, 64), device=dev, dtype=torch.float16)
+    k = _rand((B, L, 64), dev, 1).half()
+    v = _ints((B, L, 64), -8, 8, dev, 2)
+    v[:, 0] = v[:, 0] - v.sum(1)  # column sums exactly zero except row 0 adjusts -> mean = 0
+    out = torch.empty((B, L, 64), device=dev, dtype=torch.float16)
+    ops.attention(q, k, v.half(), out, nb0=B, nb1=1, heads=H, lq=L, lk=L, q_strides=(L * 64, 0, 64),
+                  k_strides=(L * 64, 0, 64), o_strides=(L * 64, 0, 64))
+    assert out.float().abs().max() < 1e-3
+
+
+def test_attention_one_hot_keys(dev):
+    """Huge logits make softmax one-hot: out[q] must equal V[perm[q]] -> checks the key<->value
+    pairing of the transposed-V operand (asymmetric, every row distinct)."""
+    from seva import ops
+    L = 128
+    perm = torch.randperm(L, generator=torch.Generator().manual_seed(3))
+    eye = torch.eye(64)
+    k = torch.zeros(L, 64)
+    q = torch.zeros(L, 64)
+    # give key j a unique +-1 code in 64 dims; query i copies the code of key perm[i] (x40)
+    codes = torch.sign(torch.randn(L, 64, generator=torch.Generator().manual_seed(4)))
+    k[:] = codes
+    q[:] = codes[perm] * 40.0
+    v = _ints((L, 64), -20, 20, torch.device("cpu"), 5)
+    out = torch.empty((1, L, 64), device=dev, dtype=torch.float16)
+    ops.attention(q.half().to(dev)[None], k.half().to(dev)[None], v.half().to(dev)[None], out,
+                  nb0=1, nb1=1, heads=1, lq=L, lk=L, q_strides=(L * 64, 0, 64),
+                  k_strides=(L * 64, 0, 64), o_strides=(L * 64, 0, 64))
+    ref = _attn_ref(q[None, None], k[None, None], v[None, None], 0.125)[0]
+    assert rel_l2(out.cpu(), ref) < 2e-3
+    assert torch.equal(out[0].float().cpu().round(), v[perm])
+
+
+@pytest.mark.parametrize("T,S,H", [(21, 50, 2), (4, 36, 1), (24, 9, 5)])
+def test_attention_temporal_strided(dev, T, S, H):
+    """Temporal regime: tokens = frames, batch = (b, pixel); read in place from [(b t), s, 3C]."""
+    from seva import ops
+    B, C = 2, 64 * H
+    qkv = _rand((B * T, S, 3 * C), dev, 11).half()
+    out = torch.full((B * T, S, C), float("nan"), device=dev, dtype=torch.float16)
+    ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], out, nb0=B, nb1=S, heads=H,
+                  lq=T, lk=T, q_strides=(T * S * 3 * C, 3 * C, S * 3 * C),
+                  k_strides=(T * S * 3 * C, 3 * C, S * 3 * C), o_strides=(T * S * C, C, S * C))
+    x = qkv.view(B, T, S, 3, H, 64).permute(3, 0, 2, 4, 1, 5)  # [3, B, S, H, T, 64]
+    ref = _attn_ref(x[0], x[1], x[2], 0.125)  # [B,S,H,T,64]
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(B * T, S, C)
+    assert rel_l2(out, ref) < 2e-3
+
+
+GN_CASES = [  # n, hw, c1, c2, silu, dense
+    (3, 81, 64, 0, False, False), (2, 100, 64, 32, True, True), (4, 324, 320, 0, True, True),
+    (2, 50, 1280, 640, True, True), (2, 36, 1280, 1280, True, False), (2, 37, 640, 320, True, True),
+    (1, 5184, 320, 0, True, False),
+]
+
+
+@pytest.mark.parametrize("n,hw,c1,c2,silu,dense", GN_CASES)
+def test_groupnorm(dev, n, hw, c1, c2, silu, dense):
+    from seva import ops
+    C = c1 + c2
+    x1 = _rand((n, hw, c1), dev, 1) * 2 + 0.5
+    x2 = _rand((n, hw, c2), dev, 2) - 1.0 if c2 else None
+    gamma, beta = 1 + 0.1 * _rand((C,), dev, 3), 0.1 * _rand((C,), dev, 4)
+    dmap = _rand((n, hw, 6), dev, 5) if dense else None
+    dw = _rand((2 * C, 6), dev, 6, 0.3) if dense else None
+    db = _rand((2 * C,), dev, 7, 0.1) if dense else None
+    out = torch.full((n, hw, C), float("nan"), device=dev, dtype=torch.float16)
+    ws = ops.groupnorm_workspace(n, dev)
+    eps = 1e-6 if not silu else 1e-5
+    ops.groupnorm(x1, x2, gamma, beta, out, ws, eps=eps, silu=silu, dense=dmap, dense_w=dw, dense_b=db)
+    x = torch.cat([x1, x2], -1) if c2 else x1
+    ref = F.group_norm(x.transpose(1, 2), 32, gamma, beta, eps).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    if dense:
+        d = dmap @ dw.T + db
+        ref = ref * (1 + d[..., :C]) + d[..., C:]
+    err = rel_l2(out, ref)
+    assert err < 6e-4, f"rel_l2 {err}"
+    assert (out.float() - ref).abs().max() < 2e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("rows,c", [(10, 64), (1001, 320), (333, 640), (50, 1280), (7, 128)])
+def test_layernorm(dev, rows, c):
+    from seva import ops
+    x = _rand((rows, c), dev, 1) * 3 + 1
+    g, b = 1 + 0.1 * _rand((c,), dev, 2), 0.1 * _rand((c,), dev, 3)
+    out = torch.empty((rows, c), device=dev, dtype=torch.float16)
+    ops.layernorm(x, g, b, out)
+    ref = F.layer_norm(x, (c,), g, b, 1e-5)
+    assert rel_l2(out, ref) < 6e-4
+    assert (out.float() - ref).abs().max() < 4e-3
+
+
+def test_layout_and_elementwise(dev):
+    from seva import ops
+    n, h, w = 3, 7, 5
+    x1, x2 = _rand((n, 4, h, w), dev, 1), _rand((n, 7, h, w), dev, 2)
+    sc = _rand((n,), dev, 3).abs() + 0.5
+    out = torch.full((n, h * w, 64), float("nan"), device=dev, dtype=torch.float16)
+    ops.nchw_to_nhwc_f16(x1, x2, out, scale=sc)
+    ref = torch.cat([x1 * sc[:, None, None, None], x2], 1).permute(0, 2, 3, 1).reshape(n, h * w, 11)
+    assert torch.equal(out[..., :11], ref.half()) and out[..., 11:].abs().max() == 0
+    y = _rand((n, h * w, 8), dev, 4)
+    o = torch.empty((n, 4, h, w), device=dev)
+    ops.nhwc_to_nchw_f32(y, o)
+    assert torch.equal(o, y[..., :4].reshape(n, h, w, 4).permute(0, 3, 1, 2))
+    a, b = _rand((10, 64), dev, 5), _rand((10, 32), dev, 6)
+    cc = torch.empty((10, 96), device=dev, dtype=torch.float16)
+    ops.cast_concat_f16(a, b, cc)
+    assert torch.equal(cc, torch.cat([a, b], 1).half())
+    src = _rand((n, 6, 12, 10), dev, 7)
+    for oh, ow in ((6, 5), (3, 3), (12, 10), (1, 1), (24, 20)):
+        ob = torch.empty((n, oh * ow, 6), device=dev)
+        ops.bilinear_to_nhwc(src, ob, oh, ow)
+        refb = F.interpolate(src, size=(oh, ow), mode="bilinear", align_corners=True)
+        assert torch.allclose(ob.view(n, oh, ow, 6).permute(0, 3, 1, 2), refb, atol=2e-6), (oh, ow)
+    t = torch.tensor([999, 979, 500, 19, 0], device=dev)
+    for dim in (320, 64):
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half).to(dev)
+        te = torch.empty((5, dim), device=dev, dtype=torch.float16)
+        ops.timestep_embedding_f16(t, freqs, te)
+        args = t[:, None].float().cpu() * freqs.cpu()[None]
+        reft = torch.cat([torch.cos(args), torch.sin(args)], -1)
+        assert (te.float().cpu() - reft).abs().max() < 1.5e-3
+    s = torch.empty((10, 64), device=dev, dtype=torch.float16)
+    ops.silu_f16(a, s)
+    assert (s.float() - F.silu(a)).abs().max() < 2e-3
+    ad = torch.empty_like(a)
+    ops.add_f32(a, a * 2, ad)
+    assert torch.equal(ad, a + a * 2)
+
+
+def test_sampler_elementwise(dev):
+    from seva import ops
+    T, c, h, w = 4, 4, 6, 5
+    x = _rand((T, c, h, w), dev, 1) * 10
+    rep = _rand((T, c + 1, h, w), dev, 2)
+    rep[:, c] = (torch.arange(T, device=dev) % 2).float()[:, None, None]
+    o = torch.empty_like(x)
+    ops.replace_blend(x, rep, o)
+    m = rep[:, c:]
+    assert torch.equal(o, x * (1 - m) + rep[:, :c] * m)
+    net = _rand((T, c, h, w), dev, 3)
+    co, cs = -torch.rand(T, device=dev) * 5, torch.ones(T, device=dev)
+    ops.denoiser_combine(net, x, co, cs, o)
+    assert torch.allclose(o, net * co[:, None, None, None] + x * cs[:, None, None, None], rtol=1e-6, atol=1e-6)
+    eps, ns = _rand((T, c, h, w), dev, 4), torch.rand(T, device=dev)
+    ops.add_noise(x, eps, ns, o)
+    assert torch.allclose(o, x + eps * ns[:, None, None, None], rtol=1e-6, atol=1e-6)
+    den2 = _rand((2 * T, c, h, w), dev, 5)
+    scale = torch.tensor([1.2, 2.0, 1.5, 2.0], device=dev)
+    sh, dt = torch.full((T,), 3.1, device=dev), torch.full((T,), -1.7, device=dev)
+    ops.cfg_euler(x, den2, scale, sh, dt, o)
+    u, cnd = den2.chunk(2)
+    den = u + scale[:, None, None, None] * (cnd - u)
+    ref = x + dt[:, None, None, None] * ((x - den) / sh[:, None, None, None])
+    assert torch.allclose(o, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_errors_are_loud(dev):
+    from seva import ops
+    from seva._native import SevaNativeError
+    a = torch.zeros((8, 100), device=dev, dtype=torch.float16)  # K not a multiple of 64
+    w = torch.zeros((8, 100), device=dev, dtype=torch.float16)
+    with pytest.raises(SevaNativeError):
+        ops.gemm(a, w, out_f32=torch.empty((8, 8), device=dev))
+    with pytest.raises(SevaNativeError):
+        ops.gemm(a.cpu(), w.cpu(), out_f32=torch.empty((8, 8)))
