@@ -1,0 +1,167 @@
+"""TEST-ONLY torch emulation of the C-ABI operators (same layouts, strides and epilogue contracts
+as include/seva_hip.h).  Lets the CPU suite check the *host logic* of `seva._engine` (buffer
+wiring, strides, weight packing, residual plumbing) without a GPU.  Never imported by the product.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu):
+    if geglu:
+        if bias is not None:
+            acc = acc + bias
+        g = acc.view(M, N // 64, 2, 32)
+        acc = (g[:, :, 0] * F.gelu(g[:, :, 1])).reshape(M, N // 2)
+    else:
+        if bias is not None:
+            acc = acc + bias
+        if row_add is not None:
+            ld = ld_row_add or N
+            ng = (M + rows_per_group - 1) // rows_per_group
+            ra = torch.as_strided(row_add, (ng, N), (ld, 1), row_add.storage_offset())
+            acc = acc + ra.repeat_interleave(rows_per_group, 0)[:M]
+        if residual is not None:
+            acc = acc + residual.reshape(M, -1)[:, :N]
+    if out_f32 is not None:
+        out_f32.view(M, -1)[:, : acc.shape[1]].copy_(acc)
+    if out_f16 is not None:
+        out_f16.view(M, -1)[:, : acc.shape[1]].copy_(acc.half())
+
+
+def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, residual=None,
+         out_f32=None, out_f16=None, geglu=False):
+    assert a.dtype == F16 and w.dtype == F16 and a.shape[1] % 64 == 0
+    M, N = a.shape[0], w.shape[0]
+    acc = a.float() @ w.float().T
+    _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu)
+
+
+def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
+            ld_row_add=0, residual=None, out_f32=None, out_f16=None):
+    n, ih, iw, cin = x.shape
+    assert x.dtype == F16 and cin % 64 == 0 and w.shape[1] == 9 * cin
+    xi = x.float().permute(0, 3, 1, 2)
+    if upsample:
+        xi = F.interpolate(xi, scale_factor=2, mode="nearest")
+    wk = w.float().view(-1, 3, 3, cin).permute(0, 3, 1, 2)
+    y = F.conv2d(xi, wk, None, stride=stride, padding=1)
+    N = w.shape[0]
+    acc = y.permute(0, 2, 3, 1).reshape(-1, N)
+    _epilogue(acc, acc.shape[0], N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32,
+              out_f16, False)
+
+
+def attention(q, k, v, out, *, nb0, nb1, heads, lq, lk, q_strides, k_strides, o_strides, scale=0.125):
+    def view(t, st, L):
+        return torch.as_strided(t, (nb0, nb1, L, heads, 64), (st[0], st[1], st[2], 64, 1), t.storage_offset())
+    qv, kv, vv = view(q, q_strides, lq).float(), view(k, k_strides, lk).float(), view(v, k_strides, lk).float()
+    att = torch.einsum("abqhd,abkhd->abhqk", qv, kv) * scale
+    o = torch.einsum("abhqk,abkhd->abqhd", torch.softmax(att, -1), vv)
+    view(out, o_strides, lq).copy_(o.half())
+
+
+def groupnorm_workspace(n, device):
+    return torch.empty(n * 64 * 32 * 2, dtype=F32, device=device)
+
+
+def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, silu=False,
+              dense=None, dense_w=None, dense_b=None):
+    x = torch.cat([x1, x2], -1) if x2 is not None else x1
+    C = x.shape[-1]
+    y = F.group_norm(x.transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2)
+    if silu:
+        y = F.silu(y)
+    if dense is not None:
+        d = dense @ dense_w.T + dense_b
+        y = y * (1 + d[..., :C]) + d[..., C:]
+    out_f16.copy_(y.half())
+
+
+def layernorm(x, gamma, beta, out_f16, eps=1e-5):
+    c = x.shape[-1]
+    out_f16.view(-1, c).copy_(F.layer_norm(x.reshape(-1, c), (c,), gamma, beta, eps).half())
+
+
+def nchw_to_nhwc_f16(x1, x2, out_f16, scale=None):
+    n = x1.shape[0]
+    a = x1 if scale is None else x1 * scale.view(-1, 1, 1, 1)
+    x = torch.cat([a, x2], 1) if x2 is not None else a
+    c = x.shape[1]
+    o = out_f16.view(n, -1, out_f16.shape[-1])
+    o.zero_()
+    o[..., :c] = x.reshape(n, c, -1).transpose(1, 2).half()
+
+
+def nhwc_to_nchw_f32(x, out):
+    n, c = out.shape[:2]
+    out.copy_(x[..., :c].reshape(n, out.shape[2], out.shape[3], c).permute(0, 3, 1, 2))
+
+
+def cast_concat_f16(x1, x2, out_f16):
+    c1 = x1.shape[-1]
+    a = x1.reshape(-1, c1)
+    x = torch.cat([a, x2.reshape(a.shape[0], -1)], 1) if x2 is not None else a
+    out_f16.view(a.shape[0], -1).copy_(x.half())
+
+
+def bilinear_to_nhwc(src, out, oh, ow):
+    y = F.interpolate(src, size=(oh, ow), mode="bilinear", align_corners=True)
+    out.copy_(y.permute(0, 2, 3, 1).reshape(out.shape))
+
+
+def timestep_embedding_f16(t, freqs, out_f16):
+    args = t[:, None].float() * freqs[None]
+    out_f16.copy_(torch.cat([torch.cos(args), torch.sin(args)], -1).half())
+
+
+def silu_f16(x, out_f16):
+    out_f16.copy_(F.silu(x).half())
+
+
+def add_f32(a, b, out):
+    out.copy_(a + b)
+
+
+def _rows(v, x):
+    return v.view(-1, *([1] * (x.ndim - 1)))
+
+
+def replace_blend(x, replace, out):
+    c = x.shape[1]
+    m = replace[:, c:]
+    out.copy_(x * (1 - m) + replace[:, :c] * m)
+
+
+def denoiser_combine(net, x, c_out, c_skip, out):
+    out.copy_(net * _rows(c_out, x) + x * _rows(c_skip, x))
+
+
+def add_noise(x, eps, noise_scale, out):
+    out.copy_(x + eps * _rows(noise_scale, x))
+
+
+def cfg_combine(den2, scale, out):
+    u, c = den2.chunk(2)
+    out.copy_(u + _rows(scale, u) * (c - u))
+
+
+def euler_step(x, den, sigma_hat, dt, out):
+    out.copy_(x + _rows(dt, x) * ((x - den) / _rows(sigma_hat, x)))
+
+
+def cfg_euler(x, den2, scale, sigma_hat, dt, out):
+    u, c = den2.chunk(2)
+    den = u + _rows(scale, u) * (c - u)
+    out.copy_(x + _rows(dt, x) * ((x - den) / _rows(sigma_hat, x)))
+
+
+def to_d(x, den, sigma, out):
+    out.copy_((x - den) / _rows(sigma, x))
+
+
+def scale_rows(x, s, out):
+    out.copy_(x * _rows(s, x))

@@ -88,7 +88,7 @@ def test_tiny_forward_vs_golden_and_layers(dev, tiny):
     assert err < NET_TOL
 
 
-@pytest.mark.parametrize("T,h,w", [(3, 12, 20), (2, 8, 8), (5, 16, 8)])
+@pytest.mark.parametrize("T,h,w", [(3, 8, 24), (2, 8, 8), (5, 16, 8)])
 def test_tiny_forward_odd_shapes(dev, tiny, T, h, w):
     """Ragged sizes: M-tails in every GEMM, partial attention tiles, non-square images."""
     from oracle import seva_ref as O
