@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 from conftest import load_golden, rel_l2
 
-NET_TOL = 2e-3      # one full network call, fp16 operands / fp32 accumulate vs fp32 oracle
-LAYER_TOL = 3e-3    # any single layer output inside the network (errors compound along depth)
+NET_TOL = 1e-3      # north_star tolerance: rel-L2 per denoised latent, fp16 operands vs fp32 oracle
+LAYER_TOL = 1e-3    # every layer output inside the network
 
 
 @pytest.fixture(scope="module")
@@ -177,7 +177,7 @@ def test_tiny_sampler_loop_vs_golden(dev, tiny):
     y = _sampler_run(net, dev, int(g["T"]), int(g["hw"]), int(g["steps"]), list(g["eps"]))
     err = rel_l2(y.cpu(), g["y"])
     print(f"tiny 4-step sampler loop vs reference golden: rel-L2 {err:.3e}")
-    assert err < 4e-3  # four network calls compound
+    assert err < 2e-3  # four chained network calls
 
 
 def test_guiders_and_denoiser_vs_golden(dev, tiny):
@@ -239,4 +239,4 @@ def test_full_sampler_loop_vs_golden(dev, full):
     y = _sampler_run(net, dev, int(g["T"]), int(g["hw"]), int(g["steps"]), list(g["eps"]))
     err = rel_l2(y.cpu(), g["y"])
     print(f"1.3B 4-step sampler loop (config 1) vs reference golden: rel-L2 {err:.3e}")
-    assert err < 4e-3
+    assert err < 2e-3
