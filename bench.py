@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- denoising steps/sec of the Seva 1.3B hot path on MI355X (driver contract).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one Euler-EDM sampler step over one 21-view window at 576x576 (latent 72x72): noise
+perturbation, CFG-batched network call on 2T = 42 frames, guidance combine, Euler update
+(reference seva/sampling.py:347-368).  Inputs are synthetic (seva/synthetic.py) and resident in
+HBM before the timed region; weights are random-init of the 1.3B architecture.
+
+N > 1: the windows of a long trajectory are independent work units; every rank
+denoises its own window with replicated weights ("weak" scaling), after one RCCL all-gather of the
+anchor latents that adjacent windows share.  value = (steps of all ranks) / max-over-ranks time.
+
+Extra objects on the JSON line: `roofline` (dominant kernel class, algorithmic FLOP / HIP-event
+time measured live in one instrumented step) and `cpu_baseline` (the CPU oracle timed on the
+host cores on BASELINE config 1, rank 0, N=1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+# reference-equivalent dense FLOP per denoising step (FlopCounterMode on the reference)
+FLOP_PER_STEP = {(21, 72): 7.691e13, (8, 72): 2.634e13, (24, 72): 8.999e13, (4, 32): 2.217e12}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_model(device, shapes_only=False):
+    from seva import synthetic as synth
+    from seva.model import Seva, SevaParams
+
+    with torch.device("meta"):
+        net = Seva(SevaParams())
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    t0 = time.time()
+    sd = synth.synth_state_dict(shapes, 0)
+    log(f"[bench] synthetic 1.3B weights generated on CPU in {time.time() - t0:.1f}s")
+    net.load_state_dict(sd, strict=True, assign=True)
+    return net, sd
+
+
+def make_sampler(net, device, T, hw, steps, seed):
+    from seva import sampling as S
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+
+    sc = synth.synth_scene(T, (hw, hw), (0,), seed=seed)
+    disc = S.DDPMDiscretization()
+    den = S.DiscreteDenoiser(disc, num_idx=1000, device=device)
+    sampler = S.EulerEDMSampler(disc, S.MultiviewCFG(1.2), num_steps=steps, verbose=False,
+                                device=device, s_churn=0.0)
+    wrap = SGMWrapper(net)
+    cond = {k: v.to(device) for k, v in sc["cond"].items()}
+    uc = {k: v.to(device) for k, v in sc["uc"].items()}
+    gk = dict(c2w=sc["c2w"].to(device), K=sc["K"].to(device),
+              input_frame_mask=sc["input_frame_mask"].to(device))
+    denoise = lambda x, s, c: den(wrap, x, s, c, num_frames=T)  # noqa: E731
+    return sampler, denoise, sc["noise"].to(device), cond, uc, gk
+
+
+def cpu_baseline(sd):
+    """CPU oracle (restatement pinned to the reference, oracle/) on BASELINE config 1:
+    T=4, 32x32 latent, CFG batch 8 -- bounded sample: 2 sampler steps."""
+    from oracle import sampling_ref as SR
+    from oracle import seva_ref as OR
+    from seva import synthetic as synth
+
+    T, hw, steps = 4, 32, 2
+    sc = synth.synth_scene(T, (hw, hw), (0,), seed=23)
+    net = lambda x, idx, c, num_frames: OR.sgm_wrapper_forward(sd, x, idx, c, num_frames)  # noqa: E731
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        SR.euler_edm_sample(net, sc["noise"], sc["cond"], sc["uc"], steps, 2.0, None, guider=1,
+                            cfg_min=1.2, c2w=sc["c2w"], K=sc["K"],
+                            input_frame_mask=sc["input_frame_mask"])
+    dt = time.time() - t0
+    return {
+        "value": steps / dt, "unit": "denoising steps/s", "cores": cores, "kind": "port",
+        "sample": f"{steps} Euler steps of BASELINE config 1 (T=4, 32x32 latent, CFG batch 8, fp32), "
+                  f"{dt:.1f}s; {FLOP_PER_STEP[(4, 32)] * steps / dt / 1e12:.2f} TFLOP/s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--views", type=int, default=21, help="frames per window (T)")
+    ap.add_argument("--latent", type=int, default=72, help="latent side (576/8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from seva import _native, ops
+    from seva.distributed import exchange_anchor_latents
+
+    _native.load()
+    T, hw, K, Wm = args.views, args.latent, args.steps, args.warmup
+    net, sd = build_model(device)
+    net = net.to(device).eval()
+    total_steps = K + Wm
+    sampler, denoise, noise, cond, uc, gk = make_sampler(net, device, T, hw, max(total_steps, 2), 23 + rank)
+
+    # anchors shared by adjacent windows (first-pass output; here: this rank's input-view latent)
+    anchors = cond["replace"][:1, :4].contiguous()
+    x, s_in, sigmas, num_sigmas, cond, uc = sampler.prepare_sampling_loop(noise, cond, uc, None)
+
+    def step(i, xx):
+        return sampler.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoise, xx, 2.0, cond, uc,
+                                    0.0, **gk)
+
+    with torch.no_grad():
+        for i in range(Wm):
+            x = step(i, x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        if world > 1:
+            exchange_anchor_latents(anchors)
+        for i in range(Wm, Wm + K):
+            x = step(i, x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    if not torch.isfinite(x).all():
+        raise SystemExit("non-finite sampler state")
+    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    roofline = None
+    if not args.no_roofline:
+        ops.prof_enable(True)
+        with torch.no_grad():
+            step(min(Wm + K, num_sigmas - 2), x)
+        prof = ops.prof_collect()
+        ops.prof_enable(False)
+        mm = {k: prof[k] for k in ("gemm", "conv", "attention")}
+        dom = max(mm, key=lambda k: mm[k]["ms"])
+        d = mm[dom]
+        ach = d["work"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        roofline = {
+            "bound": "mfma", "kernel": {"gemm": "gemm_kernel<plain>", "conv": "gemm_kernel<conv3x3>",
+                                        "attention": "attn_kernel"}[dom],
+            "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
+            "launches": d["launches"], "avg_launch_ms": d["ms"] / max(d["launches"], 1),
+            "classes_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "classes_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)
+                               for k, v in mm.items()},
+        }
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(sd)
+        flop = FLOP_PER_STEP.get((T, hw))
+        value = world * K / elapsed
+        out = {
+            "metric": "denoising steps/sec, 1.3B Seva @ 21x576x576 views",
+            "value": value, "unit": "denoising steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "novel_views_per_sec": value * (T - 1) / 50.0,
+            "config": {"workload": f"Seva 1.3B (1,263,968,004 params, random-init), one {T}-view window per GPU, "
+                                   f"{hw * 8}x{hw * 8} px (latent {hw}x{hw}), CFG batch {2 * T}, Euler-EDM step, "
+                                   "MultiviewCFG(1.2) cfg 2.0; novel_views_per_sec assumes 50 steps/window",
+                       "views": T, "latent": hw, "windows": world,
+                       "flop_per_step": flop,
+                       "model_tflops": (flop * value / 1e12) if flop else None},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
