@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--latent", type=int, default=72, help="latent side (576/8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,6 +185,24 @@ def main():
                                for k, v in mm.items()},
         }
 
+    vae = None
+    if rank == 0 and not args.no_vae:
+        # VAE decode of finished latents (reference autoencoder.py:40-48, chunk_size=1), outside `value`
+        from seva.modules.autoencoder import AutoEncoder
+
+        ae = AutoEncoder(chunk_size=1).to(device)
+        zl = (x[:2] / x[:2].std() * 0.18215).contiguous()
+        with torch.no_grad():
+            ae.decode(zl[:1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            img = ae.decode(zl)
+            torch.cuda.synchronize()
+        dtv = (time.perf_counter() - t1) / zl.shape[0]
+        vae = {"ms_per_frame": dtv * 1e3, "frames_per_sec": 1.0 / dtv, "frame": f"{img.shape[-2]}x{img.shape[-1]}",
+               "weights": "random-init SD-2.1 VAE decoder topology (parity unpinned)"}
+        del ae
+
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -202,7 +221,7 @@ def main():
                        "views": T, "latent": hw, "windows": world,
                        "flop_per_step": flop,
                        "model_tflops": (flop * value / 1e12) if flop else None},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "vae_decode": vae,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

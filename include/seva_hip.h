@@ -127,6 +127,13 @@ int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
 int seva_layernorm_f16(const float* x, const float* gamma, const float* beta, void* out_f16,
                        int64_t rows, int32_t c, float eps, seva_stream_t stream);
 
+/* Row softmax: out[r][c] = softmax_c(x[r][c] * scale) as f16 for c < cols; columns cols..cols_pad-1
+ * of `out` are written as 0 (so `out` can be the K-padded A operand of the following P*V GEMM).
+ * Used for the single-head, d=512 attention of the VAE mid block, which runs as
+ * GEMM(QK^T) -> softmax -> GEMM(PV) (diffusers AutoencoderKL decoder, reference autoencoder.py:38). */
+int seva_softmax_rows_f16(const float* x, int64_t ldx, void* out_f16, int64_t ldo, int64_t rows,
+                          int32_t cols, int32_t cols_pad, float scale, seva_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Layout / elementwise helpers.
  */

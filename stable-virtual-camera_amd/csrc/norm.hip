@@ -210,6 +210,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           half_t* __restrict__ out, int64_t ldo,
+                                                           int cols, int cols_pad, float scale_log2) {
+  __shared__ float red[4];
+  const float* xr = x + (int64_t)blockIdx.x * ldx;
+  half_t* orow = out + (int64_t)blockIdx.x * ldo;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = -1e30f;
+  for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, xr[c] * scale_log2);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s += __builtin_amdgcn_exp2f(xr[c] * scale_log2 - mx);
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int c = threadIdx.x; c < cols_pad; c += 256)
+    orow[c] = (half_t)(c < cols ? __builtin_amdgcn_exp2f(xr[c] * scale_log2 - mx) * inv : 0.f);
+}
+
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 }  // namespace
@@ -262,4 +286,17 @@ extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const floa
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta,
                      (half_t*)out_f16, rows, c, eps);
   return seva_check_launch("layernorm_kernel");
+}
+
+extern "C" int seva_softmax_rows_f16(const float* x, int64_t ldx, void* out_f16, int64_t ldo,
+                                     int64_t rows, int32_t cols, int32_t cols_pad, float scale,
+                                     seva_stream_t stream) {
+  SEVA_REQUIRE(x && out_f16 && rows > 0 && cols > 0 && cols_pad >= cols && ldx >= cols && ldo >= cols_pad,
+               "softmax_rows: bad args");
+  SEVA_REQUIRE(rows <= 0x7fffffff, "softmax_rows: too many rows");
+  hipStream_t s = (hipStream_t)stream;
+  SevaProfScope prof(3, (double)rows * cols * 6.0, s);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, ldx,
+                     (half_t*)out_f16, ldo, cols, cols_pad, scale * 1.44269504088896340736f);
+  return seva_check_launch("softmax_rows_kernel");
 }

@@ -74,7 +74,8 @@ class _Arena:
 
 
 class SevaEngine:
-    def __init__(self, model):
+    @staticmethod
+    def _resolve_device(model) -> torch.device:
         params = [p for p in model.parameters()]
         if not params or params[0].device.type != "cuda":
             raise SevaNativeError(
@@ -84,7 +85,10 @@ class SevaEngine:
         from . import _native
 
         _native.load()
-        self.device = params[0].device
+        return params[0].device
+
+    def __init__(self, model):
+        self.device = self._resolve_device(model)
         self.p = model.params
         self.layout: Layout = model._layout
         self.arena = _Arena(self.device)

@@ -1,0 +1,172 @@
+"""HIP execution of the SD-2.1 VAE decoder (reference seva/modules/autoencoder.py:37-48 ->
+diffusers AutoencoderKL.decode).  Same kernels and layout rules as the UNet engine: channels-last
+fp32 stream, fp16 GEMM operands, 3x3 convs as implicit GEMM with the nearest-2x upsample fused
+into the gather.  The single-head d=512 mid-block attention runs as GEMM(QK^T) -> row softmax ->
+GEMM(P V^T) with V produced already transposed by swapping the GEMM operand roles; the value
+bias is added after P*V (rows of P sum to 1, exact).
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._engine import CIN_PAD, _Arena, pack_conv3x3
+from ._native import SevaNativeError, require_cuda
+
+F16, F32 = torch.float16, torch.float32
+
+
+class VaeDecoderEngine:
+    @staticmethod
+    def _resolve_device(weights) -> torch.device:
+        params = list(weights.parameters())
+        if not params or params[0].device.type != "cuda":
+            raise SevaNativeError("AutoEncoder.decode runs only on an AMD GPU (no CPU fallback): call .to('cuda')")
+        from . import _native
+
+        _native.load()
+        return params[0].device
+
+    def __init__(self, weights):
+        self.device = self._resolve_device(weights)
+        self.block_out = weights.block_out
+        self.out_channels = weights.out_channels
+        self.latent = weights.latent_channels
+        self.arena = _Arena(self.device)
+        sd = {k: v.detach().to(self.device) for k, v in weights.state_dict().items()}
+        W = {}
+
+        def conv3(p, cin_pad=None, cout_pad=None):
+            w, b = sd[p + ".weight"].float(), sd[p + ".bias"].float()
+            if cout_pad and cout_pad > w.shape[0]:
+                w = torch.cat([w, w.new_zeros((cout_pad - w.shape[0],) + tuple(w.shape[1:]))], 0)
+                b = torch.cat([b, b.new_zeros(cout_pad - b.shape[0])], 0)
+            W[p + ".w"], W[p + ".b"] = pack_conv3x3(w, cin_pad), b.contiguous()
+
+        def lin(p, src=None):
+            src = src or p
+            w = sd[src + ".weight"].float()
+            W[p + ".w"] = w.reshape(w.shape[0], -1).to(F16).contiguous()
+            W[p + ".b"] = sd[src + ".bias"].float().contiguous()
+
+        def norm(p):
+            W[p + ".g"], W[p + ".b"] = sd[p + ".weight"].float().contiguous(), sd[p + ".bias"].float().contiguous()
+
+        for k in list(sd):
+            if not k.endswith(".weight"):
+                continue
+            p = k[: -len(".weight")]
+            shp = sd[k].shape
+            if len(shp) == 1:
+                norm(p)
+            elif len(shp) == 2 or shp[-1] == 1:
+                if p != "post_quant_conv":
+                    lin(p)
+            elif p == "decoder.conv_in":
+                conv3(p, cin_pad=CIN_PAD)
+            elif p == "decoder.conv_out":
+                conv3(p, cout_pad=4)
+            else:
+                conv3(p)
+        # post_quant_conv (1x1, 4->4) as a GEMM over the 64-channel padded latent image
+        wq = torch.zeros((self.latent, CIN_PAD), dtype=F16, device=self.device)
+        wq[:, : self.latent] = sd["post_quant_conv.weight"].reshape(self.latent, self.latent).to(F16)
+        W["post_quant_conv.w"], W["post_quant_conv.b"] = wq, sd["post_quant_conv.bias"].float().contiguous()
+        self.W = W
+
+    def _buf(self, name, shape, dtype, zero=False):
+        key = (name, tuple(int(s) for s in shape), dtype)
+        fresh = key not in self.arena.bufs
+        t = self.arena.get(name, shape, dtype)
+        if fresh and zero:
+            t.zero_()
+        return t
+
+    def _resnet(self, p, x, n, h, w, cin, cout):
+        """diffusers ResnetBlock2D (no time embedding): GN-SiLU-conv-GN-SiLU-conv + shortcut."""
+        W, hw = self.W, h * w
+        a16 = self._buf("gn16", (n, hw, cin), F16)
+        ops.groupnorm(x, None, W[p + ".norm1.g"], W[p + ".norm1.b"], a16, self.gn_ws, eps=1e-6, silu=True)
+        mid = self._buf("v_mid", (n, hw, cout), F32)
+        ops.conv3x3(a16.view(n, h, w, cin), W[p + ".conv1.w"], bias=W[p + ".conv1.b"], out_f32=mid)
+        b16 = self._buf("gn16", (n, hw, cout), F16)
+        ops.groupnorm(mid, None, W[p + ".norm2.g"], W[p + ".norm2.b"], b16, self.gn_ws, eps=1e-6, silu=True)
+        if cin != cout:
+            xs16 = self._buf("v_sk16", (n * hw, cin), F16)
+            ops.cast_concat_f16(x, None, xs16)
+            res = self._buf("v_sk32", (n * hw, cout), F32)
+            ops.gemm(xs16, W[p + ".conv_shortcut.w"], bias=W[p + ".conv_shortcut.b"], out_f32=res)
+        else:
+            res = x
+        out = self._buf("out:" + p, (n, hw, cout), F32)
+        ops.conv3x3(b16.view(n, h, w, cout), W[p + ".conv2.w"], bias=W[p + ".conv2.b"], residual=res, out_f32=out)
+        return out
+
+    def _attention(self, p, x, n, h, w, c):
+        """Single-head self-attention over h*w tokens of dim c (diffusers Attention in the VAE mid block)."""
+        W, hw = self.W, h * w
+        hw_pad = 64 * ((hw + 63) // 64)
+        g16 = self._buf("gn16", (n, hw, c), F16)
+        ops.groupnorm(x, None, W[p + ".group_norm.g"], W[p + ".group_norm.b"], g16, self.gn_ws, eps=1e-6, silu=False)
+        q = self._buf("v_q", (n * hw, c), F16)
+        k = self._buf("v_k", (n * hw, c), F16)
+        ops.gemm(g16.view(n * hw, c), W[p + ".to_q.w"], bias=W[p + ".to_q.b"], out_f16=q)
+        ops.gemm(g16.view(n * hw, c), W[p + ".to_k.w"], bias=W[p + ".to_k.b"], out_f16=k)
+        att = self._buf("v_att", (n * hw, c), F16)
+        vT = self._buf("v_vT", (c, hw_pad), F16, zero=True)       # V^T, zero beyond hw
+        sc = self._buf("v_sc", (hw, hw_pad), F32)
+        pr = self._buf("v_pr", (hw, hw_pad), F16)
+        for i in range(n):
+            gi = g16.view(n, hw, c)[i]
+            ops.gemm(W[p + ".to_v.w"], gi, out_f16=vT)             # [c, hw] = W_v @ x_i^T (bias folded below)
+            ops.gemm(q[i * hw:(i + 1) * hw], k[i * hw:(i + 1) * hw], out_f32=sc)
+            ops.softmax_rows(sc, pr, hw, 1.0 / (c**0.5))
+            ops.gemm(pr, vT, bias=W[p + ".to_v.b"], out_f16=att[i * hw:(i + 1) * hw])
+        out = self._buf("out:" + p, (n, hw, c), F32)
+        ops.gemm(att, W[p + ".to_out.0.w"], bias=W[p + ".to_out.0.b"], residual=x.view(n * hw, c),
+                 out_f32=out.view(n * hw, c))
+        return out
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, scale_factor: float) -> torch.Tensor:
+        require_cuda(z)
+        W = self.W
+        z = z.to(F32).contiguous()
+        n, cz, h, w = z.shape
+        if cz != self.latent:
+            raise ValueError(f"expected {self.latent} latent channels, got {cz}")
+        self.gn_ws = self._buf("gn_ws", (n * 64 * 32 * 2,), F32)
+        inv = torch.full((n,), 1.0 / scale_factor, dtype=F32, device=self.device)
+        z16 = self._buf("v_z16", (n, h * w, CIN_PAD), F16)
+        ops.nchw_to_nhwc_f16(z, None, z16, scale=inv)                      # z / 0.18215, channels-last, padded
+        pq = self._buf("v_pq16", (n * h * w, CIN_PAD), F16, zero=True)      # cols >= 4 stay zero
+        ops.gemm(z16.view(n * h * w, CIN_PAD), W["post_quant_conv.w"], bias=W["post_quant_conv.b"], out_f16=pq)
+        top = self.block_out[-1]
+        x = self._buf("out:conv_in", (n, h * w, top), F32)
+        ops.conv3x3(pq.view(n, h, w, CIN_PAD), W["decoder.conv_in.w"], bias=W["decoder.conv_in.b"], out_f32=x)
+        x = self._resnet("decoder.mid_block.resnets.0", x, n, h, w, top, top)
+        x = self._attention("decoder.mid_block.attentions.0", x, n, h, w, top)
+        x = self._resnet("decoder.mid_block.resnets.1", x, n, h, w, top, top)
+        rev = list(reversed(self.block_out))
+        cin = rev[0]
+        for i, cout in enumerate(rev):
+            for j in range(3):
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, n, h, w, cin if j == 0 else cout, cout)
+            cin = cout
+            if i != len(rev) - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                x16 = self._buf("v_up16", (n, h, w, cout), F16)
+                ops.cast_concat_f16(x, None, x16)
+                h, w = 2 * h, 2 * w
+                x = self._buf("out:" + p, (n, h * w, cout), F32)
+                ops.conv3x3(x16, W[p + ".w"], upsample=True, bias=W[p + ".b"], out_f32=x)
+        c = rev[-1]
+        g16 = self._buf("gn16", (n, h * w, c), F16)
+        ops.groupnorm(x, None, W["decoder.conv_norm_out.g"], W["decoder.conv_norm_out.b"], g16, self.gn_ws,
+                      eps=1e-6, silu=True)
+        o4 = self._buf("v_o4", (n, h * w, 4), F32)
+        ops.conv3x3(g16.view(n, h, w, c), W["decoder.conv_out.w"], bias=W["decoder.conv_out.b"], out_f32=o4)
+        out = torch.empty((n, self.out_channels, h, w), dtype=F32, device=self.device)
+        ops.nhwc_to_nchw_f32(o4, out)
+        return out

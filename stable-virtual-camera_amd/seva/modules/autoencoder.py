@@ -1,0 +1,125 @@
+"""`seva.modules.autoencoder` -- drop-in for the reference wrapper (seva/modules/autoencoder.py).
+
+The reference delegates to `diffusers.AutoencoderKL.from_pretrained("stabilityai/stable-diffusion-2-1-base",
+subfolder="vae")` (autoencoder.py:12-17).  Neither diffusers nor the weights are available offline, so this
+module owns (a) a parameter holder with diffusers' decoder key names (`post_quant_conv.*`, `decoder.*`), so a
+real `diffusion_pytorch_model.safetensors` loads with `load_state_dict(strict=False)`, and (b) the decode path
+on the HIP kernels (`seva/_vae_engine.py`).  Parity with diffusers is UNPINNED (no fixture can be made here);
+tests compare against our own restatement of the published topology.
+
+Kept API: `AutoEncoder(chunk_size=None)`, `.encode(x, chunk_size)`, `.decode(z, chunk_size)`, `.to(device)`,
+`scale_factor`, `downsample`.  `encode` is a next-row item and raises.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+from torch import nn
+
+BLOCK_OUT = (128, 256, 512, 512)
+LAYERS_PER_BLOCK = 2
+
+
+class _Holder(nn.Module):
+    def put(self, path: str, module: nn.Module) -> None:
+        head, _, rest = path.partition(".")
+        if not rest:
+            self.add_module(head, module)
+            return
+        if head not in self._modules:
+            self.add_module(head, _Holder())
+        self._modules[head].put(rest, module)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder; compute runs in the HIP engine")
+
+
+class VaeDecoderWeights(_Holder):
+    """Decoder half of the SD-2.1 AutoencoderKL (published config), diffusers key names."""
+
+    def __init__(self, block_out=BLOCK_OUT, latent_channels: int = 4, out_channels: int = 3):
+        super().__init__()
+        self.block_out, self.latent_channels, self.out_channels = tuple(block_out), latent_channels, out_channels
+        top = block_out[-1]
+
+        def resnet(p, cin, cout):
+            self.put(p + ".norm1", nn.GroupNorm(32, cin, eps=1e-6))
+            self.put(p + ".conv1", nn.Conv2d(cin, cout, 3, padding=1))
+            self.put(p + ".norm2", nn.GroupNorm(32, cout, eps=1e-6))
+            self.put(p + ".conv2", nn.Conv2d(cout, cout, 3, padding=1))
+            if cin != cout:
+                self.put(p + ".conv_shortcut", nn.Conv2d(cin, cout, 1))
+
+        self.put("post_quant_conv", nn.Conv2d(latent_channels, latent_channels, 1))
+        self.put("decoder.conv_in", nn.Conv2d(latent_channels, top, 3, padding=1))
+        resnet("decoder.mid_block.resnets.0", top, top)
+        a = "decoder.mid_block.attentions.0"
+        self.put(a + ".group_norm", nn.GroupNorm(32, top, eps=1e-6))
+        for n in ("to_q", "to_k", "to_v"):
+            self.put(f"{a}.{n}", nn.Linear(top, top))
+        self.put(a + ".to_out.0", nn.Linear(top, top))
+        resnet("decoder.mid_block.resnets.1", top, top)
+        rev = list(reversed(block_out))
+        cin = rev[0]
+        for i, cout in enumerate(rev):
+            for j in range(LAYERS_PER_BLOCK + 1):
+                resnet(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+            cin = cout
+            if i != len(rev) - 1:
+                self.put(f"decoder.up_blocks.{i}.upsamplers.0.conv", nn.Conv2d(cout, cout, 3, padding=1))
+        self.put("decoder.conv_norm_out", nn.GroupNorm(32, rev[-1], eps=1e-6))
+        self.put("decoder.conv_out", nn.Conv2d(rev[-1], out_channels, 3, padding=1))
+
+
+class AutoEncoder(nn.Module):
+    scale_factor: float = 0.18215
+    downsample: int = 8
+
+    def __init__(self, chunk_size: int | None = None):
+        super().__init__()
+        self.module = VaeDecoderWeights()
+        path = os.environ.get("SEVA_VAE_PATH")  # local diffusers VAE safetensors, if the user has one
+        if path:
+            import safetensors.torch
+
+            self.module.load_state_dict(safetensors.torch.load_file(path), strict=False)
+        self.module.eval().requires_grad_(False)
+        self.chunk_size = chunk_size
+        self._engine = None
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def engine(self):
+        if self._engine is None:
+            from .._vae_engine import VaeDecoderEngine
+
+            self._engine = VaeDecoderEngine(self.module)
+        return self._engine
+
+    def _encode(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(
+            "VAE encode is not part of this round's hot path (SURVEY.md §8f N1); decode only."
+        )
+
+    def encode(self, x: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
+        return self._encode(x)
+
+    def _decode(self, z: torch.Tensor) -> torch.Tensor:
+        return self.engine().decode(z, self.scale_factor)
+
+    def decode(self, z: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
+        chunk_size = chunk_size or self.chunk_size
+        if chunk_size is not None:
+            return torch.cat([self._decode(zc) for zc in z.split(chunk_size)], dim=0)
+        return self._decode(z)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.decode(self.encode(x))

@@ -164,6 +164,15 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_f16:
           "seva_layernorm_f16")
 
 
+def softmax_rows(x: torch.Tensor, out_f16: torch.Tensor, cols: int, scale: float) -> None:
+    """x: [rows, >=cols] f32 -> out_f16: [rows, cols_pad] f16 = softmax(x[:, :cols]*scale), zero padded."""
+    require_cuda(x, out_f16)
+    rows = x.shape[0]
+    check(_lib().seva_softmax_rows_f16(x.data_ptr(), x.stride(0), out_f16.data_ptr(), out_f16.stride(0),
+                                       rows, cols, out_f16.shape[1], scale, stream_ptr(x.device)),
+          "seva_softmax_rows_f16")
+
+
 def nchw_to_nhwc_f16(x1: torch.Tensor, x2: torch.Tensor | None, out_f16: torch.Tensor,
                      scale: torch.Tensor | None = None) -> None:
     require_cuda(x1, out_f16)

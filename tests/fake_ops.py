@@ -86,6 +86,11 @@ def layernorm(x, gamma, beta, out_f16, eps=1e-5):
     out_f16.view(-1, c).copy_(F.layer_norm(x.reshape(-1, c), (c,), gamma, beta, eps).half())
 
 
+def softmax_rows(x, out_f16, cols, scale):
+    out_f16.zero_()
+    out_f16[:, :cols] = torch.softmax(x[:, :cols] * scale, -1).half()
+
+
 def nchw_to_nhwc_f16(x1, x2, out_f16, scale=None):
     n = x1.shape[0]
     a = x1 if scale is None else x1 * scale.view(-1, 1, 1, 1)

@@ -74,11 +74,12 @@ def _cpu_engine(tag="tiny"):
     with torch.device("meta"):
         net = Seva(params)
     net.load_state_dict(sd, strict=True, assign=True)
-    eng = object.__new__(_engine.SevaEngine)
-    eng.device = torch.device("cpu")
-    eng.p, eng.layout = net.params, net._layout
-    eng.arena = _engine._Arena(eng.device)
-    eng._pack(net)
+    orig = _engine.SevaEngine.__dict__["_resolve_device"]
+    _engine.SevaEngine._resolve_device = staticmethod(lambda m: torch.device("cpu"))  # test seam
+    try:
+        eng = _engine.SevaEngine(net)
+    finally:
+        _engine.SevaEngine._resolve_device = orig
     return eng, sd
 
 
@@ -190,3 +191,29 @@ def test_hip_path_fails_loudly_on_cpu():
                  out_f32=torch.zeros(4, 4))
     with pytest.raises(SevaNativeError):
         S.VanillaCFG()(torch.zeros(4, 4, 2, 2), torch.ones(2), 2.0)
+
+
+def test_vae_decoder_orchestration_vs_restatement(monkeypatch):
+    """VAE decode engine (emulated kernels) vs oracle/vae_ref.py.  Parity with diffusers is UNPINNED."""
+    from oracle import vae_ref as V
+    from seva import _vae_engine, synthetic as synth
+    from seva.modules.autoencoder import VaeDecoderWeights
+    monkeypatch.setattr(_vae_engine, "ops", fake_ops)
+    monkeypatch.setattr(_vae_engine, "require_cuda", lambda *a: None)
+    monkeypatch.setattr(_vae_engine.VaeDecoderEngine, "_resolve_device", staticmethod(lambda w: torch.device("cpu")))
+    full = {k: tuple(v.shape) for k, v in VaeDecoderWeights().state_dict().items()}
+    assert full == V.decoder_shapes()
+    small = (64, 64, 128, 128)  # same topology, narrower: keeps the CPU test fast
+    wts = VaeDecoderWeights(block_out=small)
+    shapes = V.decoder_shapes(block_out=small)
+    assert {k: tuple(v.shape) for k, v in wts.state_dict().items()} == shapes
+    sd = synth.synth_state_dict(shapes, 3)
+    wts.load_state_dict(sd)
+    eng = _vae_engine.VaeDecoderEngine(wts)
+    z = torch.randn(2, 4, 6, 5, generator=torch.Generator().manual_seed(0)) * 0.18215 * 4
+    out = eng.decode(z, 0.18215)
+    ref = V.vae_decode(sd, z)
+    assert out.shape == (2, 3, 48, 40)
+    err = rel_l2(out, ref)
+    print(f"vae decode (emulated kernels) vs restatement: {err:.2e}")
+    assert err < 3e-3
