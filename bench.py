@@ -85,7 +85,12 @@ def cpu_baseline(sd):
     T, hw, steps = 4, 32, 2
     sc = synth.synth_scene(T, (hw, hw), (0,), seed=23)
     net = lambda x, idx, c, num_frames: OR.sgm_wrapper_forward(sd, x, idx, c, num_frames)  # noqa: E731
-    cores = torch.get_num_threads()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))  # the GPU box grants a 16-core share per GPU
+    torch.set_num_threads(cores)
     t0 = time.time()
     with torch.no_grad():
         SR.euler_edm_sample(net, sc["noise"], sc["cond"], sc["uc"], steps, 2.0, None, guider=1,

@@ -106,6 +106,8 @@ class VaeDecoderEngine:
     def _attention(self, p, x, n, h, w, c):
         """Single-head self-attention over h*w tokens of dim c (diffusers Attention in the VAE mid block)."""
         W, hw = self.W, h * w
+        if hw % 4:
+            raise ValueError(f"VAE attention needs h*w % 4 == 0 (got {h}x{w}); latents are multiples of 8 per side")
         hw_pad = 64 * ((hw + 63) // 64)
         g16 = self._buf("gn16", (n, hw, c), F16)
         ops.groupnorm(x, None, W[p + ".group_norm.g"], W[p + ".group_norm.b"], g16, self.gn_ws, eps=1e-6, silu=False)

@@ -210,10 +210,10 @@ def test_vae_decoder_orchestration_vs_restatement(monkeypatch):
     sd = synth.synth_state_dict(shapes, 3)
     wts.load_state_dict(sd)
     eng = _vae_engine.VaeDecoderEngine(wts)
-    z = torch.randn(2, 4, 6, 5, generator=torch.Generator().manual_seed(0)) * 0.18215 * 4
+    z = torch.randn(2, 4, 6, 6, generator=torch.Generator().manual_seed(0)) * 0.18215 * 4
     out = eng.decode(z, 0.18215)
     ref = V.vae_decode(sd, z)
-    assert out.shape == (2, 3, 48, 40)
+    assert out.shape == (2, 3, 48, 48)
     err = rel_l2(out, ref)
     print(f"vae decode (emulated kernels) vs restatement: {err:.2e}")
     assert err < 3e-3
