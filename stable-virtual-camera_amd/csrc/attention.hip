@@ -52,9 +52,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   constexpr int PASSES = (KT * 8) / NT;     // 16-byte chunks per thread per tile (K and V each)
   static_assert((KT * 8) % NT == 0, "tile/threads mismatch");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128];
-  char* const lds_k = smem;
-  char* const lds_v = smem + KT * 128;
+  // double-buffered K/V tiles: [buf][K tile | V tile]
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];
+  constexpr int BUF_BYTES = 2 * KT * 128;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -87,7 +87,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+  // m_run is the exponent reference in the log2 domain (scaled scores); it may lag the true running
+  // max by up to RESCALE_THR (deferred rescale), so probabilities are bounded by 2^RESCALE_THR.
+  constexpr float RESCALE_THR = 8.0f;
   float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale_log2;
 
   const int nt = (p.lk + KT - 1) / KT;
   uint4 kreg[PASSES], vreg[PASSES];
@@ -103,21 +107,25 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
       vreg[ps] = *(const uint4*)(vbase + off);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    char* const lk_ = smem + buf * BUF_BYTES;
+    char* const lv_ = lk_ + KT * 128;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int row = lr + ps * (NT / 8);
-      *(uint4*)(lds_k + row * 128 + (k_chunk_swz(row, lc) << 4)) = kreg[ps];
-      *(uint4*)(lds_v + row * 128 + (v_chunk_swz(row, lc) << 4)) = vreg[ps];
+      *(uint4*)(lk_ + row * 128 + (k_chunk_swz(row, lc) << 4)) = kreg[ps];
+      *(uint4*)(lv_ + row * 128 + (v_chunk_swz(row, lc) << 4)) = vreg[ps];
     }
   };
 
   load_tile(0);
+  store_tile(0);
+  if (nt > 1) load_tile(1);
+  __syncthreads();
+  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
   for (int kt = 0; kt < nt; ++kt) {
-    __syncthreads();  // previous tile fully consumed
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < nt) load_tile(kt + 1);  // in flight during the math below
+    const char* const lds_k = smem + (kt & 1) * BUF_BYTES;
+    const char* const lds_v = lds_k + KT * 128;
 
     // ---- S^T = K Q^T ----
     f32x16 sc[KB];
@@ -133,25 +141,34 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
         sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
       }
     }
-    // ---- online softmax (log2 domain) ----
-    const bool partial = (kt + 1) * KT > p.lk;
+    // ---- tail mask: only the last tile can hold keys >= lk (block-uniform branch) ----
+    if ((kt + 1) * KT > p.lk) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= p.lk) sc[kb][r] = -1e30f;
+        }
+    }
+    // ---- online softmax, log2 domain, deferred rescale ----
     float mx = -1e30f;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float t = sc[kb][r] * p.scale_log2;
-        if (partial) {
-          const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= p.lk) t = -1e30f;
-        }
-        sc[kb][r] = t;
-        mx = fmaxf(mx, t);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    const float mxs = mx * c;  // c > 0
+    if (__any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
+      const float m_new = fmaxf(m_run, mxs);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+    }
     float lsum = 0.f;
     half8_t pf[KB][2];
 #pragma unroll
@@ -160,18 +177,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_amdgcn_exp2f(sc[kb][8 * s2 + j] - m_new);
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + j], c, -m_run));
           lsum += e;
           pf[kb][s2][j] = (half_t)e;
         }
-    l_run = l_run * alpha + lsum;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+    l_run += lsum;
 
     // ---- O^T += V^T P^T ----
-    const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
 #pragma unroll
@@ -198,6 +210,12 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
         }
       }
     }
+    // ---- stage tile kt+1 into the other buffer (its last readers passed the previous barrier) ----
+    if (kt + 1 < nt) {
+      store_tile((kt + 1) & 1);
+      if (kt + 2 < nt) load_tile(kt + 2);
+    }
+    __syncthreads();
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

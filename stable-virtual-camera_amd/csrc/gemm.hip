@@ -35,6 +35,7 @@ struct GemmArgs {
   int64_t rows_per_group, ldra;
   int32_t n, ih, iw, cin, oh, ow, stride, upsample;
   int32_t tiles_m, tiles_n;
+  int32_t n_chunks;  // each block walks tiles_n / n_chunks consecutive N-tiles of one M-tile
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -68,10 +69,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  // block -> (M-tile, chunk of N-tiles).  A block walks its N-tiles itself: the A row-panel is
+  // fetched from HBM by the first tile and re-read from L2 by the others, instead of 8..80 sibling
+  // blocks all stalling on the same HBM miss for every K-tile.
+  const int work = xcd_remap(blockIdx.x, p.tiles_m * p.n_chunks);
+  const int tm = work / p.n_chunks, chunk = work - tm * p.n_chunks;
+  const int tn_begin = (int)((int64_t)chunk * p.tiles_n / p.n_chunks);
+  const int tn_end = (int)((int64_t)(chunk + 1) * p.tiles_n / p.n_chunks);
   const int64_t m0 = (int64_t)tm * BM;
-  const int64_t n0 = (int64_t)tn * BN;
 
   // ---- staging state: lane (r = lane>>3, phys chunk = lane&7) of each 8-row wave-instruction ----
   const int sr = lane >> 3, sp = lane & 7;
@@ -102,14 +107,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
   }
   const half_t* b_ptr[B_PASSES];
+  auto set_b_tile = [&](int tn) {
 #pragma unroll
-  for (int i = 0; i < B_PASSES; ++i) {
-    const int row = wave * (BN / 4) + 8 * i + sr;
-    const int q = sp ^ ((row >> 1) & 7);
-    int64_t n = n0 + row;
-    if (n >= p.N) n = p.N - 1;
-    b_ptr[i] = p.w + n * p.K + q * 8;
-  }
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int row = wave * (BN / 4) + 8 * i + sr;
+      const int q = sp ^ ((row >> 1) & 7);
+      int64_t n = (int64_t)tn * BN + row;
+      if (n >= p.N) n = p.N - 1;
+      b_ptr[i] = p.w + n * p.K + q * 8;
+    }
+  };
 
   auto stage = [&](int buf, int kt) {
     char* const la = lds_a + buf * A_BYTES + wave * (BM / 4) * 128;
@@ -137,85 +144,124 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     for (int i = 0; i < B_PASSES; ++i) glds16(b_ptr[i] + (int64_t)kt * BK, lb + i * 1024);
   };
 
-  f32x4 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int fr = lane & 15, fg = lane >> 4;  // fragment row / k-group
   const int nk = (int)(p.K / BK);
 
+  set_b_tile(tn_begin);
   stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* const ta = lds_a + cur * A_BYTES;
-    const char* const tb = lds_b + cur * B_BYTES;
+  for (int tn = tn_begin; tn < tn_end; ++tn) {
+    const int64_t n0 = (int64_t)tn * BN;
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      half8_t af[MI], bf[NJ];
-      const int q = 4 * s + fg;
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();  // stage 0 of this tile has landed (vmcnt(0) + barrier)
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      const char* const ta = lds_a + cur * A_BYTES;
+      const char* const tb = lds_b + cur * B_BYTES;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        half8_t af[MI], bf[NJ];
+        const int q = 4 * s + fg;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = wm * WM + 16 * i + fr;
+          af[i] = *(const half8_t*)(ta + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int row = wn * WN + 16 * j + fr;
+          bf[j] = *(const half8_t*)(tb + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    // both LDS buffers are free: start the next tile's first stage before the epilogue
+    if (tn + 1 < tn_end) {
+      set_b_tile(tn + 1);
+      stage(0, 0);
+    }
+
+    // ---- epilogue: lane holds features f..f+3 (rows of D) of token m (column of D) ----
+    if (EPI == 0) {
+      // per 16-row block: issue every addend load (bias is hoisted; row_add and residual = 8
+      // independent 16-byte loads in flight), then add + store
+      f32x4 bj[NJ];
+      int64_t fj[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+        if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
+        fj[j] = f;
+        bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int row = wm * WM + 16 * i + fr;
-        af[i] = *(const half8_t*)(ta + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
-      }
+        const int64_t m = m0 + wm * WM + 16 * i + fr;
+        const int64_t mc = m < p.M ? m : p.M - 1;
+        f32x4 ra[NJ], rv[NJ];
+        if (p.row_add) {
+          const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int row = wn * WN + 16 * j + fr;
-        bf[j] = *(const half8_t*)(tb + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
-      }
+          for (int j = 0; j < NJ; ++j) ra[j] = *(const f32x4*)(rp + fj[j]);
+        }
+        if (p.residual) {
+          const float* rp = p.residual + mc * p.ldr;
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+          for (int j = 0; j < NJ; ++j) rv[j] = *(const f32x4*)(rp + fj[j]);
+        }
+        if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane holds features f..f+3 (rows of D) of token m (column of D) ----
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int64_t m = m0 + wm * WM + 16 * i + fr;
-    if (m >= p.M) continue;
-    const int64_t grp = (p.row_add != nullptr) ? m / p.rows_per_group : 0;
-    if (EPI == 0) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
-        if (f >= p.N) continue;
-        f32x4 v = acc[i][j];
-        if (p.bias) v += *(const f32x4*)(p.bias + f);
-        if (p.row_add) v += *(const f32x4*)(p.row_add + grp * p.ldra + f);
-        if (p.residual) v += *(const f32x4*)(p.residual + m * p.ldr + f);
-        if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v;
-        if (p.out_f16) {
-          half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+        for (int j = 0; j < NJ; ++j) {
+          const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+          if (f >= p.N) continue;
+          f32x4 v = acc[i][j] + bj[j];
+          if (p.row_add) v += ra[j];
+          if (p.residual) v += rv[j];
+          if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v;
+          if (p.out_f16) {
+            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+          }
         }
       }
     } else {
       // wave's 64 weight rows = [16 v | 16 v | 16 g | 16 g] -> 32 output features
+      f32x4 bv[2], bg[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int64_t fv = n0 + wn * WN + 16 * j + 4 * fg;  // interleaved-row index of the value
-        if (fv >= p.N) continue;
-        f32x4 v = acc[i][j], g = acc[i][j + 2];
-        if (p.bias) {
-          v += *(const f32x4*)(p.bias + fv);
-          g += *(const f32x4*)(p.bias + fv + 32);
-        }
-        const int64_t fo = (n0 + wn * WN) / 2 + 16 * j + 4 * fg;
-        f32x4 o;
+        int64_t fv = n0 + wn * WN + 16 * j + 4 * fg;  // interleaved-row index of the value
+        if (fv > p.N - 36) fv = p.N - 36;
+        bv[j] = p.bias ? *(const f32x4*)(p.bias + fv) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bg[j] = p.bias ? *(const f32x4*)(p.bias + fv + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = v[r] * gelu_erf_f(g[r]);
-        if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o;
-        if (p.out_f16) {
-          half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-          *(half4_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
+      for (int i = 0; i < MI; ++i) {
+        const int64_t m = m0 + wm * WM + 16 * i + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t fv = n0 + wn * WN + 16 * j + 4 * fg;
+          if (fv >= p.N) continue;
+          const f32x4 v = acc[i][j] + bv[j], g = acc[i][j + 2] + bg[j];
+          const int64_t fo = (n0 + wn * WN) / 2 + 16 * j + 4 * fg;
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = v[r] * gelu_erf_f(g[r]);
+          if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o;
+          if (p.out_f16) {
+            half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            *(half4_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
+          }
         }
       }
     }
@@ -234,7 +280,14 @@ int launch(const GemmArgs& a, hipStream_t s) {
   GemmArgs args = a;
   args.tiles_m = (int)((a.M + BM - 1) / BM);
   args.tiles_n = (int)((a.N + BN - 1) / BN);
-  const int64_t nb = (int64_t)args.tiles_m * args.tiles_n;
+  // enough blocks for two full waves of the chip (256 CUs x 2 resident blocks), otherwise each block
+  // keeps its M-tile and walks as many N-tiles as that allows
+  constexpr int kTargetBlocks = 1024;
+  int chunks = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;
+  if (chunks < 1) chunks = 1;
+  if (chunks > args.tiles_n) chunks = args.tiles_n;
+  args.n_chunks = chunks;
+  const int64_t nb = (int64_t)args.tiles_m * chunks;
   if (nb <= 0 || nb > 0x7fffffff) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;

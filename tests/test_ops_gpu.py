@@ -324,3 +324,29 @@ def test_errors_are_loud(dev):
         ops.gemm(a, w, out_f32=torch.empty((8, 8), device=dev))
     with pytest.raises(SevaNativeError):
         ops.gemm(a.cpu(), w.cpu(), out_f32=torch.empty((8, 8)))
+
+
+@pytest.mark.parametrize("slope", [3.0, 0.05, -2.0])
+def test_attention_running_max_paths(dev, slope):
+    """Scores that grow along the key axis force the online-softmax rescale on every tile
+    (slope 3 -> +192 per 64-key tile), exercise the deferred-rescale path (slope 0.05: the
+    exponent reference lags by < 2^8 for several tiles before one rescale) and the never-rescale
+    path (negative slope: the first tile holds the max)."""
+    from seva import ops
+    B, H, L = 2, 2, 512
+    C = 64 * H
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, L, C, generator=g) * 0.5
+    k = torch.randn(B, L, C, generator=g) * 0.5
+    v = torch.randn(B, L, C, generator=g)
+    # dimension 0 of every head carries a ramp: q[...,0] = 1, k[...,0] = 8*slope*key  (logit scale 1/8)
+    q[:, :, ::64] = 1.0
+    k[:, :, ::64] = (torch.arange(L, dtype=torch.float32) * slope * 8.0)[None, :, None]
+    qh, kh, vh = q.half().to(dev), k.half().to(dev), v.half().to(dev)
+    out = torch.empty(B, L, C, device=dev, dtype=torch.float16)
+    ops.attention(qh, kh, vh, out, nb0=B, nb1=1, heads=H, lq=L, lk=L, q_strides=(L * C, 0, C),
+                  k_strides=(L * C, 0, C), o_strides=(L * C, 0, C))
+    r = lambda t: t.float().view(B, L, H, 64).transpose(1, 2)
+    ref = _attn_ref(r(qh), r(kh), r(vh), 0.125).transpose(1, 2).reshape(B, L, C)
+    err = rel_l2(out, ref)
+    assert torch.isfinite(out.float()).all() and err < 2e-3, f"slope {slope}: rel_l2 {err}"
