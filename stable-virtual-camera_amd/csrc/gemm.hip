@@ -14,43 +14,13 @@
 // The conv variant gathers the A tile straight from the NHWC image (per-lane source address per
 // (ky,kx) tap, zero page for padding, optional stride 2 or nearest-2x upsampled source), so
 // im2col / F.interpolate outputs never exist in HBM.
-#include "seva_common.h"
+#include "gemm_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
-
-__device__ uint4 g_zero_page[8];  // 128 B of zeros: source of padding taps (zero-initialised)
-
-struct GemmArgs {
-  const half_t* a;
-  const half_t* w;
-  const float* bias;
-  const float* row_add;
-  const float* residual;
-  float* out_f32;
-  half_t* out_f16;
-  int64_t M, N, K;
-  int64_t lda, ldr, ldo32, ldo16;
-  int64_t rows_per_group, ldra;
-  int32_t n, ih, iw, cin, oh, ow, stride, upsample;
-  int32_t tiles_m, tiles_n;
-  int32_t n_chunks;  // each block walks tiles_n / n_chunks consecutive N-tiles of one M-tile
-};
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0,
-                                   0);
-}
-
-// Bijective XCD-aware remap (blocks b, b+8, ... share an XCD): each XCD gets one contiguous run of
-// logical tiles, so the A row-panel it streams is fetched into that XCD's L2 once.
-__device__ __forceinline__ int xcd_remap(int bid, int nb) {
-  const int q = nb >> 3, r = nb & 7, x = bid & 7;
-  const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-  return start + (bid >> 3);
-}
 
 template <int BM, int BN, int MODE, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
@@ -196,40 +166,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       // per 16-row block: issue every addend load (bias is hoisted; row_add and residual = 8
       // independent 16-byte loads in flight), then add + store
       f32x4 bj[NJ];
-      int64_t fj[NJ];
+      int fj[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
         if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
-        fj[j] = f;
+        fj[j] = (int)f;
         bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int64_t m = m0 + wm * WM + 16 * i + fr;
         const int64_t mc = m < p.M ? m : p.M - 1;
-        f32x4 ra[NJ], rv[NJ];
+        // loads AND arithmetic are unconditional (clamped addresses) so that no load result is
+        // left pending across the loop back-edge (hipcc would protect the register reuse with a
+        // vmcnt(0) that also drains the LDS-DMA ring); only the stores are guarded
+        f32x4 v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] = acc[i][j] + bj[j];
         if (p.row_add) {
           const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) ra[j] = *(const f32x4*)(rp + fj[j]);
+          for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
         }
         if (p.residual) {
           const float* rp = p.residual + mc * p.ldr;
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) rv[j] = *(const f32x4*)(rp + fj[j]);
+          for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
         }
-        if (m >= p.M) continue;
+        const bool row_ok = m < p.M;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
-          if (f >= p.N) continue;
-          f32x4 v = acc[i][j] + bj[j];
-          if (p.row_add) v += ra[j];
-          if (p.residual) v += rv[j];
-          if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v;
+          if (!row_ok || f >= p.N) continue;
+          if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v[j];
           if (p.out_f16) {
-            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            half4_t h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
             *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
           }
         }
@@ -349,9 +321,15 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (d->epilogue == 1) {
     SEVA_REQUIRE(d->N % 64 == 0, "geglu: N=%lld not a multiple of 64", (long long)d->N);
     SEVA_REQUIRE(d->mode == 0, "geglu: plain mode only");
-    return launch<128, 128, 0, 1>(a, s);
   }
   const bool narrow = d->N <= 32;
+  // kernel choice: SEVA_GEMM_CFG = 0 (128x128 two-stage), 1 (256x128x64 ring), 2 (256x256x32 ring)
+  // overrides the shape heuristic (benchmarking knob)
+  int cfg = -1;
+  if (const char* e = getenv("SEVA_GEMM_CFG")) cfg = atoi(e);
+  if (cfg < 0) cfg = 0;
+  if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
+  if (d->epilogue == 1) return launch<128, 128, 0, 1>(a, s);
   if (d->mode == 0) return narrow ? launch<128, 32, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
   return narrow ? launch<128, 32, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
 }

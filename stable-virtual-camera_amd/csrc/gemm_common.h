@@ -1,0 +1,39 @@
+// Shared by gemm.hip (128x128 two-stage kernel) and gemm_ring.hip (8-wave multi-stage ring kernel).
+#pragma once
+#include "seva_common.h"
+
+static __device__ uint4 g_zero_page[8];  // 128 B of zeros: source of padding taps (zero-initialised)
+
+struct SevaGemmArgs {
+  const half_t* a;
+  const half_t* w;
+  const float* bias;
+  const float* row_add;
+  const float* residual;
+  float* out_f32;
+  half_t* out_f16;
+  int64_t M, N, K;
+  int64_t lda, ldr, ldo32, ldo16;
+  int64_t rows_per_group, ldra;
+  int32_t n, ih, iw, cin, oh, ow, stride, upsample;
+  int32_t tiles_m, tiles_n;
+  int32_t n_chunks;  // each block walks tiles_n / n_chunks consecutive N-tiles of one M-tile
+};
+typedef SevaGemmArgs GemmArgs;
+
+static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0,
+                                   0);
+}
+
+// Bijective XCD-aware remap (blocks b, b+8, ... share an XCD): each XCD gets one contiguous run of
+// logical tiles, so the A row-panel it streams is fetched into that XCD's L2 once.
+static __device__ __forceinline__ int xcd_remap(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = bid & 7;
+  const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + (bid >> 3);
+}
+
+// gemm_ring.hip: cfg 1 = 256x128x64 (3 stages), cfg 2 = 256x256x32 (4 stages)
+int seva_gemm_ring_launch(const GemmArgs& a, int mode, int epilogue, int cfg, hipStream_t s);
