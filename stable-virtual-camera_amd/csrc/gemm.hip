@@ -116,6 +116,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   const int fr = lane & 15, fg = lane >> 4;  // fragment row / k-group
   const int nk = (int)(p.K / BK);
+  // fragment-read byte offsets, hoisted: rows 16 apart share the swizzle term, so tile i / j of a
+  // wave is `base + i*2048` (an immediate), not a recomputed XOR per ds_read
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int ra = wm * WM + fr, rb = wn * WN + fr;
+    a_off[s] = ra * 128 + (((4 * s + fg) ^ ((ra >> 1) & 7)) << 4);
+    b_off[s] = rb * 128 + (((4 * s + fg) ^ ((rb >> 1) & 7)) << 4);
+  }
 
   set_b_tile(tn_begin);
   stage(0, 0);
@@ -136,17 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         half8_t af[MI], bf[NJ];
-        const int q = 4 * s + fg;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int row = wm * WM + 16 * i + fr;
-          af[i] = *(const half8_t*)(ta + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
-        }
+        for (int i = 0; i < MI; ++i) af[i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int row = wn * WN + 16 * j + fr;
-          bf[j] = *(const half8_t*)(tb + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
-        }
+        for (int j = 0; j < NJ; ++j) bf[j] = *(const half8_t*)(tb + b_off[s] + j * (16 * 128));
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -134,6 +134,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
     if (s < total) issue();
 
   const int fr = lane & 15, fg = lane >> 4;
+  int a_off[KSTEPS], b_off[KSTEPS];  // hoisted fragment-read offsets (swizzle term is the same for rows 16 apart)
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int ra = wm * WM + fr, rb = wn * WN + fr;
+    const int q = (BK == 64 ? 4 * s : 0) + fg;
+    a_off[s] = ra * ROWB + (swz<BK>(ra, q) << 4);
+    b_off[s] = rb * ROWB + (swz<BK>(rb, q) << 4);
+  }
   f32x4 acc[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -156,17 +164,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       half8_t af[MI], bf[NJ];
-      const int q = (BK == 64 ? 4 * s : 0) + fg;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int row = wm * WM + 16 * i + fr;
-        af[i] = *(const half8_t*)(ta + row * ROWB + (swz<BK>(row, q) << 4));
-      }
+      for (int i = 0; i < MI; ++i) af[i] = *(const half8_t*)(ta + a_off[s] + i * (16 * ROWB));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int row = wn * WN + 16 * j + fr;
-        bf[j] = *(const half8_t*)(tb + row * ROWB + (swz<BK>(row, q) << 4));
-      }
+      for (int j = 0; j < NJ; ++j) bf[j] = *(const half8_t*)(tb + b_off[s] + j * (16 * ROWB));
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll

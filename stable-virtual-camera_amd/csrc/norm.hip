@@ -10,6 +10,7 @@
 namespace {
 
 constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_THREADS = 1024;
 constexpr int GN_MAX_SLABS = 64;
 constexpr int GN_MAX_GROUPS = 32;
 constexpr int GN_MAX_DENSE = 8;
@@ -34,9 +35,10 @@ struct GnMap {
   int cq, tpp, pl_count, pl, q0, qstep;
   bool active;
   __device__ GnMap(int C) {
+    const int nthreads = blockDim.x;
     cq = C >> 2;
-    tpp = cq < GN_THREADS ? cq : GN_THREADS;  // threads per pixel
-    pl_count = GN_THREADS / tpp;
+    tpp = cq < nthreads ? cq : nthreads;  // threads per pixel
+    pl_count = nthreads / tpp;
     const int t = threadIdx.x;
     pl = t / tpp;
     q0 = t - pl * tpp;
@@ -51,7 +53,7 @@ __device__ __forceinline__ f32x4 load_quad(const GnArgs& p, int n, int pix, int 
   return *(const f32x4*)(p.x2 + ((int64_t)n * p.hw + pix) * p.c2 + (c - p.c1));
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GnArgs p) {
+__global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(GnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [pl_count][C] sums, then sumsq
   const int C = p.c1 + p.c2;
   const GnMap mp(C);
@@ -91,9 +93,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GnArgs p) {
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   __shared__ float g_mean[GN_MAX_GROUPS], g_rstd[GN_MAX_GROUPS];
   const int C = p.c1 + p.c2;
-  const GnMap mp(C);
   const int n = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
   const int cpg = C / p.groups;
+  // thread -> (pixel lane, quad): narrow tensors pack several pixels per block, wide ones are split
+  // over gridDim.z (256 quads per block); every thread owns exactly one quad of channels
+  const int cq = C >> 2;
+  int pl, pl_count, q;
+  bool active;
+  if (cq <= GN_THREADS) {
+    pl_count = GN_THREADS / cq;
+    pl = threadIdx.x / cq;
+    q = threadIdx.x - pl * cq;
+    active = pl < pl_count;
+  } else {
+    pl_count = 1;
+    pl = 0;
+    q = blockIdx.z * GN_THREADS + threadIdx.x;
+    active = q < cq;
+  }
   if ((int)threadIdx.x < p.groups) {
     const int g = threadIdx.x;
     double s = 0.0, ss = 0.0;
@@ -110,11 +127,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
     g_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
   __syncthreads();
-  if (!mp.active) return;
+  if (!active) return;
   const int p_begin = (int)((int64_t)slab * p.hw / nslab);
   const int p_end = (int)((int64_t)(slab + 1) * p.hw / nslab);
   const int dc = p.dense ? p.dense_c : 0;
-  for (int q = mp.q0; q < mp.cq; q += mp.qstep) {
+  {
     const int c0 = q * 4;
     float a[4], b[4], wsc[4][GN_MAX_DENSE], wsh[4][GN_MAX_DENSE], bsc[4], bsh[4];
 #pragma unroll
@@ -130,62 +147,83 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
         wsh[r][j] = (j < dc) ? p.dense_w[(int64_t)(C + c) * dc + j] : 0.f;
       }
     }
-    for (int pix = p_begin + mp.pl; pix < p_end; pix += mp.pl_count) {
-      const f32x4 v = load_quad(p, n, pix, c0);
-      float dn[GN_MAX_DENSE];
-      if (dc) {
-        const float* dp = p.dense + ((int64_t)n * p.hw + pix) * dc;
+    constexpr int U = 4;  // pixels in flight per thread
+    for (int pix0 = p_begin + pl; pix0 < p_end; pix0 += U * pl_count) {
+      f32x4 v[U];
+      float dn[U][GN_MAX_DENSE];
 #pragma unroll
-        for (int j = 0; j < GN_MAX_DENSE; ++j) dn[j] = (j < dc) ? dp[j] : 0.f;
-      }
-      half4_t h;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float y = v[r] * a[r] + b[r];
-        if (p.silu) y = silu_f(y);
+      for (int u = 0; u < U; ++u) {
+        int pix = pix0 + u * pl_count;
+        if (pix >= p_end) pix = p_end - 1;  // clamped duplicate load, store skipped below
+        v[u] = load_quad(p, n, pix, c0);
         if (dc) {
-          float sc = bsc[r], sh = bsh[r];
+          const float* dp = p.dense + ((int64_t)n * p.hw + pix) * dc;
 #pragma unroll
-          for (int j = 0; j < GN_MAX_DENSE; ++j) {
-            sc += wsc[r][j] * dn[j];
-            sh += wsh[r][j] * dn[j];
-          }
-          y = y * (1.0f + sc) + sh;
+          for (int j = 0; j < GN_MAX_DENSE; ++j) dn[u][j] = (j < dc) ? dp[j] : 0.f;
         }
-        h[r] = (half_t)y;
       }
-      *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pix = pix0 + u * pl_count;
+        half4_t h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y = v[u][r] * a[r] + b[r];
+          if (p.silu) y = silu_f(y);
+          if (dc) {
+            float sc = bsc[r], sh = bsh[r];
+#pragma unroll
+            for (int j = 0; j < GN_MAX_DENSE; ++j) {
+              sc += wsc[r][j] * dn[u][j];
+              sh += wsh[r][j] * dn[u][j];
+            }
+            y = y * (1.0f + sc) + sh;
+          }
+          h[r] = (half_t)y;
+        }
+        if (pix < p_end) *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+      }
     }
   }
 }
 
-constexpr int LN_MAXV = 5;  // float4 per lane -> C <= 1280
+constexpr int LN_MAXV = 20;  // float4 per lane: one 16-lane group owns a row -> C <= 1280
 
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// One 16-lane group per row (4 rows per wave, 16 per workgroup): each load instruction moves 256
+// contiguous bytes per row and a lane keeps C/64 16-byte loads in flight.
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         half_t* __restrict__ out, int64_t rows,
                                                         int c, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int sub = threadIdx.x & 15;
+  int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;
+  if (!live) row = rows - 1;  // keep the whole wave in the shuffles; store is skipped
   const int cq = c >> 2;
   const float* xr = x + row * c;
-  f32x4 v[LN_MAXV];
+  f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
-    const int i = lane + 64 * k;
+  for (int k = 0; k < NV; ++k) {
+    const int i = sub + 16 * k;
     if (i < cq) {
       v[k] = *(const f32x4*)(xr + i * 4);
       s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
     }
   }
-  const float mean = wave_sum(s) / (float)c;
+  const float mean = group16_sum(s) / (float)c;
   float ss = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
-    const int i = lane + 64 * k;
+  for (int k = 0; k < NV; ++k) {
+    const int i = sub + 16 * k;
     if (i < cq) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -194,11 +232,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+  const float rstd = rsqrtf(group16_sum(ss) / (float)c + eps);
+  if (!live) return;
   half_t* orow = out + row * c;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
-    const int i = lane + 64 * k;
+  for (int k = 0; k < NV; ++k) {
+    const int i = sub + 16 * k;
     if (i < cq) {
       const f32x4 g = *(const f32x4*)(gamma + i * 4);
       const f32x4 b = *(const f32x4*)(beta + i * 4);
@@ -249,7 +288,7 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
                "groupnorm: %d channels / %d groups unsupported", C, d->groups);
   SEVA_REQUIRE(!d->dense || (d->dense_c > 0 && d->dense_c <= GN_MAX_DENSE && d->dense_w && d->dense_b),
                "groupnorm: bad dense modulation args (dense_c=%d)", d->dense_c);
-  SEVA_REQUIRE(C <= 4 * GN_THREADS * 4, "groupnorm: C=%d too large", C);
+  SEVA_REQUIRE(C <= 4 * GN_MAX_THREADS, "groupnorm: C=%d too large", C);
   GnArgs a{};
   a.x1 = d->x1; a.x2 = d->x2; a.gamma = d->gamma; a.beta = d->beta;
   a.dense = d->dense; a.dense_w = d->dense_w; a.dense_b = d->dense_b;
@@ -257,19 +296,23 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   a.n = d->n; a.hw = d->hw; a.c1 = d->c1; a.c2 = d->c2; a.groups = d->groups;
   a.dense_c = d->dense_c; a.silu = d->silu; a.eps = d->eps;
   const int cq = C / 4;
-  const int tpp = cq < GN_THREADS ? cq : GN_THREADS;
-  const int plc = GN_THREADS / tpp;
+  // wide channel counts get a block of ~cq threads (one quad each) instead of an idle-heavy 256
+  const int nthreads = cq <= GN_THREADS ? GN_THREADS : (cq >= GN_MAX_THREADS ? GN_MAX_THREADS : 64 * ((cq + 63) / 64));
+  const int tpp = cq < nthreads ? cq : nthreads;
+  const int plc = nthreads / tpp;
   const int max_slabs = clampi(d->hw / plc, 1, GN_MAX_SLABS);
   a.nslab_stats = clampi(2048 / d->n, 1, max_slabs);
-  const int nslab_apply = clampi(4096 / d->n, 1, clampi(d->hw / plc, 1, 1024));
+  const int plc_apply = cq <= GN_THREADS ? GN_THREADS / cq : 1;
+  const int zchunks = cq <= GN_THREADS ? 1 : (cq + GN_THREADS - 1) / GN_THREADS;
+  const int nslab_apply = clampi(4096 / (d->n * zchunks), 1, clampi(d->hw / (4 * plc_apply), 1, 1024));
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)d->n * d->hw * C * (4.0 + 4.0 + 2.0);
   SevaProfScope prof(3, bytes, s);
   const size_t lds = (size_t)plc * C * 2 * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(GN_THREADS), lds, s, a);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(nthreads), lds, s, a);
   int rc = seva_check_launch("gn_stats_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nslab_apply, d->n), dim3(GN_THREADS), 0, s, a);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nslab_apply, d->n, zchunks), dim3(GN_THREADS), 0, s, a);
   return seva_check_launch("gn_apply_kernel");
 }
 
@@ -277,14 +320,21 @@ extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const floa
                                   void* out_f16, int64_t rows, int32_t c, float eps,
                                   seva_stream_t stream) {
   SEVA_REQUIRE(x && gamma && beta && out_f16, "layernorm: null pointer");
-  SEVA_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && c <= 64 * 4 * LN_MAXV,
+  SEVA_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && c <= 16 * 4 * LN_MAXV,
                "layernorm: rows=%lld c=%d unsupported", (long long)rows, c);
   hipStream_t s = (hipStream_t)stream;
   SevaProfScope prof(3, (double)rows * c * 6.0, s);
-  const int64_t blocks = (rows + 3) / 4;
+  const int64_t blocks = (rows + 15) / 16;
   SEVA_REQUIRE(blocks <= 0x7fffffff, "layernorm: too many rows");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta,
-                     (half_t*)out_f16, rows, c, eps);
+  const int nv = (c / 4 + 15) / 16;
+#define SEVA_LN_LAUNCH(NV)                                                                      \
+  hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, \
+                     beta, (half_t*)out_f16, rows, c, eps)
+  if (nv <= 2) SEVA_LN_LAUNCH(2);
+  else if (nv <= 5) SEVA_LN_LAUNCH(5);
+  else if (nv <= 10) SEVA_LN_LAUNCH(10);
+  else SEVA_LN_LAUNCH(20);
+#undef SEVA_LN_LAUNCH
   return seva_check_launch("layernorm_kernel");
 }
 
