@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
 }
 
 template <int BM, int BN, int BK, int STAGES, int WAVES_M, int WAVES_N, int MODE, int EPI>
-int launch_ring(const GemmArgs& a, hipStream_t s) {
+int launch_ring(const GemmArgs& a, hipStream_t s, int blocks_per_cu = 1) {
   constexpr int lds = STAGES * (BM + BN) * BK * 2;
   static bool attr_set = false;
   auto kern = gemm_ring_kernel<BM, BN, BK, STAGES, WAVES_M, WAVES_N, MODE, EPI>;
@@ -273,7 +273,7 @@ int launch_ring(const GemmArgs& a, hipStream_t s) {
   args.tiles_m = (int)((a.M + BM - 1) / BM);
   args.tiles_n = (int)((a.N + BN - 1) / BN);
   // one workgroup per CU is resident (LDS): aim at >= 2 rounds of 256 CUs, else keep M-tiles whole
-  constexpr int kTargetBlocks = 512;
+  const int kTargetBlocks = 512 * blocks_per_cu;
   int chunks = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;
   if (chunks < 1) chunks = 1;
   if (chunks > args.tiles_n) chunks = args.tiles_n;
@@ -290,6 +290,11 @@ int launch_ring(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int seva_gemm_ring_launch(const GemmArgs& a, int mode, int epilogue, int cfg, hipStream_t s) {
+  if (cfg == 3) {  // 128x128x32, 4 stages (64 KB LDS -> 2 workgroups per CU), waves 2x2: 64x64 per wave
+    if (epilogue == 1) return launch_ring<128, 128, 32, 4, 2, 2, 0, 1>(a, s, 2);
+    return mode == 0 ? launch_ring<128, 128, 32, 4, 2, 2, 0, 0>(a, s, 2)
+                     : launch_ring<128, 128, 32, 4, 2, 2, 1, 0>(a, s, 2);
+  }
   if (cfg == 2) {  // 256x256x32, 4 stages, waves 2(M) x 4(N): 128x64 per wave
     if (epilogue == 1) return launch_ring<256, 256, 32, 4, 2, 4, 0, 1>(a, s);
     return mode == 0 ? launch_ring<256, 256, 32, 4, 2, 4, 0, 0>(a, s)

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(GnArgs p) {
   }
 }
 
+template <bool DENSE>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   __shared__ float g_mean[GN_MAX_GROUPS], g_rstd[GN_MAX_GROUPS];
   const int C = p.c1 + p.c2;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   if (!active) return;
   const int p_begin = (int)((int64_t)slab * p.hw / nslab);
   const int p_end = (int)((int64_t)(slab + 1) * p.hw / nslab);
-  const int dc = p.dense ? p.dense_c : 0;
+  const int dc = DENSE ? p.dense_c : 0;
   {
     const int c0 = q * 4;
     float a[4], b[4], wsc[4][GN_MAX_DENSE], wsh[4][GN_MAX_DENSE], bsc[4], bsh[4];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
         wsh[r][j] = (j < dc) ? p.dense_w[(int64_t)(C + c) * dc + j] : 0.f;
       }
     }
-    constexpr int U = 4;  // pixels in flight per thread
+    constexpr int U = DENSE ? 1 : 2;  // pixels in flight per thread (register budget)
     for (int pix0 = p_begin + pl; pix0 < p_end; pix0 += U * pl_count) {
       f32x4 v[U];
       float dn[U][GN_MAX_DENSE];
@@ -312,7 +313,10 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(nthreads), lds, s, a);
   int rc = seva_check_launch("gn_stats_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nslab_apply, d->n, zchunks), dim3(GN_THREADS), 0, s, a);
+  if (d->dense)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nslab_apply, d->n, zchunks), dim3(GN_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nslab_apply, d->n, zchunks), dim3(GN_THREADS), 0, s, a);
   return seva_check_launch("gn_apply_kernel");
 }
 
