@@ -86,11 +86,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
     }
   }
   int b_row[B_PASSES], b_q[B_PASSES];
+  const half_t* b_ptr[B_PASSES];  // weight row pointers of the tile currently being ISSUED
 #pragma unroll
   for (int i = 0; i < B_PASSES; ++i) {
     b_row[i] = (wave * B_PASSES + i) * RPI + sr;
     b_q[i] = swz<BK>(b_row[i], sp);
   }
+  auto set_b_tile = [&](int tn) {
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      int64_t n = (int64_t)tn * BN + b_row[i];
+      if (n >= p.N) n = p.N - 1;
+      b_ptr[i] = p.w + n * p.K + b_q[i] * 8;
+    }
+  };
 
   auto stage = [&](int buf, int tn, int kt) {
     char* const la = smem + buf * STAGE_BYTES + wave * A_PASSES * 1024;
@@ -115,18 +124,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      int64_t n = (int64_t)tn * BN + b_row[i];
-      if (n >= p.N) n = p.N - 1;
-      glds16(p.w + n * p.K + b_q[i] * 8 + (int64_t)kt * BK, lb + i * 1024);
-    }
+    for (int i = 0; i < B_PASSES; ++i) glds16(b_ptr[i] + (int64_t)kt * BK, lb + i * 1024);
   };
 
   // issue cursor over the flattened (tile, k) sequence
   int i_tn = tn_begin, i_kt = 0, i_buf = 0;
+  set_b_tile(tn_begin);
   auto issue = [&]() {
     stage(i_buf, i_tn, i_kt);
-    if (++i_kt == nk) { i_kt = 0; ++i_tn; }
+    if (++i_kt == nk) {
+      i_kt = 0;
+      ++i_tn;
+      set_b_tile(i_tn);  // pointer math once per tile, not per stage
+    }
     if (++i_buf == STAGES) i_buf = 0;
   };
 #pragma unroll
