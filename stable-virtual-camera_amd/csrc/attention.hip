@@ -129,6 +129,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 
     // ---- S^T = K Q^T ----
     f32x16 sc[KB];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
         sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- tail mask: only the last tile can hold keys >= lk (block-uniform branch) ----
     if ((kt + 1) * KT > p.lk) {
 #pragma unroll
@@ -169,18 +171,27 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
     }
+    // P = exp2(S*c - m) packed to fp16 pairs (round-toward-zero) and the row sum taken from the
+    // ROUNDED values (v_dot2_f32_f16 with ones): numerator (P*V) and normaliser see identical
+    // probabilities, so the truncation cancels in O = sum(p v) / sum(p).
+    typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+    const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
     float lsum = 0.f;
     half8_t pf[KB][2];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        fp16x2_t pk[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + j], c, -m_run));
-          lsum += e;
-          pf[kb][s2][j] = (half_t)e;
+        for (int j = 0; j < 4; ++j) {
+          const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j], c, -m_run));
+          const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j + 1], c, -m_run));
+          pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+          lsum = __builtin_amdgcn_fdot2(pk[j], ones2, lsum, false);
         }
+        pf[kb][s2] = __builtin_bit_cast(half8_t, pk);
+      }
     l_run += lsum;
 
     // ---- O^T += V^T P^T ----

@@ -93,6 +93,12 @@ class SevaEngine:
         self.layout: Layout = model._layout
         self.arena = _Arena(self.device)
         self._pack(model)
+        # hipGraph replay of the whole network call (SEVA_HIPGRAPH=0 disables): one captured graph
+        # per input signature, fed through static input buffers
+        import os
+
+        self.use_graph = os.environ.get("SEVA_HIPGRAPH", "1") != "0"
+        self._graphs: dict = {}
 
     # ------------------------------------------------------------------ packing
     def _pack(self, model) -> None:
@@ -359,6 +365,57 @@ class SevaEngine:
             out = self._buf("out:" + spec.prefix, (n, oh * ow, c), F32)
             ops.conv3x3(x16, self.W[spec.prefix + ".w"], upsample=True, bias=self.W[spec.prefix + ".b"], out_f32=out)
         return out, oh, ow
+
+    # ------------------------------------------------------------------ graph replay
+    @torch.no_grad()
+    def forward_graphed(self, x, concat, t, y, dense_y, num_frames):
+        """Same result as `forward`, replayed from a hipGraph.  First call of a signature runs eagerly
+        twice (arena warm-up, then capture on a side stream); later calls copy the inputs into the
+        static buffers and launch the instantiated graph: one launch instead of ~550."""
+        require_cuda(x, t, y, dense_y)
+        if concat is not None and concat.numel() == 0:
+            concat = None
+        key = (tuple(x.shape), None if concat is None else tuple(concat.shape), tuple(y.shape),
+               tuple(dense_y.shape), int(num_frames))
+        ent = self._graphs.get(key)
+        if ent is None:
+            st = {
+                "x": torch.empty_like(x, dtype=F32).contiguous(),
+                "concat": None if concat is None else torch.empty_like(concat, dtype=F32).contiguous(),
+                "t": torch.empty_like(t, dtype=torch.int64).contiguous(),
+                "y": torch.empty_like(y, dtype=F32).contiguous(),
+                "dense": torch.empty_like(dense_y, dtype=F32).contiguous(),
+            }
+            self._copy_inputs(st, x, concat, t, y, dense_y)
+            out = self.forward(st["x"], st["concat"], st["t"], st["y"], st["dense"], num_frames)  # warm
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            graph = ops.Graph()
+            with torch.cuda.stream(side):
+                graph.capture_begin(self.device)
+                self.forward(st["x"], st["concat"], st["t"], st["y"], st["dense"], num_frames, out=out)
+                graph.capture_end(self.device)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            ent = (graph, st, out)
+            self._graphs[key] = ent
+        graph, st, out = ent
+        self._copy_inputs(st, x, concat, t, y, dense_y)
+        graph.launch(self.device)
+        return out.clone()
+
+    @staticmethod
+    def _copy_inputs(st, x, concat, t, y, dense_y):
+        st["x"].copy_(x)
+        if st["concat"] is not None:
+            st["concat"].copy_(concat)
+        st["t"].copy_(t)
+        st["y"].copy_(y)
+        st["dense"].copy_(dense_y)
+
+    def __call__(self, x, concat, t, y, dense_y, num_frames):
+        if self.use_graph:
+            return self.forward_graphed(x, concat, t, y, dense_y, num_frames)
+        return self.forward(x, concat, t, y, dense_y, num_frames)
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

@@ -170,7 +170,7 @@ class Seva(nn.Module):
         num_frames: int | None = None,
     ) -> torch.Tensor:
         num_frames = num_frames or self.params.num_frames
-        return self.engine().forward(x, None, t, y, dense_y, num_frames)
+        return self.engine()(x, None, t, y, dense_y, num_frames)
 
 
 class SGMWrapper(nn.Module):
@@ -185,9 +185,7 @@ class SGMWrapper(nn.Module):
             num_frames = kwargs.pop("num_frames", None) or self.module.params.num_frames
             if kwargs:
                 raise TypeError(f"unexpected arguments {sorted(kwargs)}")
-            return self.module.engine().forward(
-                x, concat, t, c["crossattn"], c["dense_vector"], num_frames
-            )
+            return self.module.engine()(x, concat, t, c["crossattn"], c["dense_vector"], num_frames)
         if concat is not None:
             x = torch.cat((x, concat), dim=1)
         return self.module(x, t=t, y=c["crossattn"], dense_y=c["dense_vector"], **kwargs)

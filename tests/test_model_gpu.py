@@ -152,6 +152,23 @@ def test_forward_is_deterministic_and_graph_replayable(dev, tiny):
     assert torch.equal(out, a)
 
 
+def test_graph_replay_equals_eager(dev, tiny):
+    """Engine default = hipGraph replay; must be bit-identical to the eager launch sequence, also when
+    inputs change between calls (static input buffers are refreshed)."""
+    net, _ = tiny
+    eng = net.engine()
+    g = torch.Generator().manual_seed(9)
+    T, h, w = 2, 8, 8
+    n = 2 * T
+    for _ in range(3):
+        x, t = torch.randn(n, 11, h, w, generator=g).to(dev), torch.randint(0, 1000, (n,), generator=g).to(dev)
+        y, dense = torch.randn(n, 1, 1024, generator=g).to(dev), torch.randn(n, 6, h, w, generator=g).to(dev)
+        a = eng.forward_graphed(x, None, t, y, dense, T)
+        b = eng.forward(x, None, t, y, dense, T)
+        assert torch.equal(a, b)
+    assert len(eng._graphs) >= 1
+
+
 def _sampler_run(net, dev, T, hw, steps, eps):
     from seva import sampling as S
     from seva import synthetic as synth
