@@ -19,6 +19,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 struct AttnArgs {
@@ -46,7 +48,7 @@ __device__ __forceinline__ int v_chunk_swz(int row, int chunk) { return chunk ^ 
 __device__ __forceinline__ int k_chunk_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 template <int NW, int KT, bool USE_TR>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int KB = KT / 32;               // 32-key blocks per tile
   constexpr int PASSES = (KT * 8) / NT;     // 16-byte chunks per thread per tile (K and V each)
@@ -118,13 +120,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     }
   };
 
-  load_tile(0);
-  store_tile(0);
-  if (nt > 1) load_tile(1);
-  __syncthreads();
   const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
-  for (int kt = 0; kt < nt; ++kt) {
-    const char* const lds_k = smem + (kt & 1) * BUF_BYTES;
+
+  // One K/V tile.  BUF (LDS buffer) and MASKED (tail tile) are compile-time so that every LDS address
+  // is `per-lane offset + immediate` and the tail mask costs nothing on full tiles.
+  auto tile = [&](auto buf_c, auto masked_c, int kt) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool MASKED = decltype(masked_c)::value;
+    const char* const lds_k = smem + BUF * BUF_BYTES;
     const char* const lds_v = lds_k + KT * 128;
 
     // ---- S^T = K Q^T ----
@@ -143,8 +146,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
       }
     }
     __builtin_amdgcn_s_setprio(0);
-    // ---- tail mask: only the last tile can hold keys >= lk (block-uniform branch) ----
-    if ((kt + 1) * KT > p.lk) {
+    if (MASKED) {  // keys >= lk exist only in the last tile
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -171,9 +173,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
     }
-    // P = exp2(S*c - m) packed to fp16 pairs (round-toward-zero) and the row sum taken from the
-    // ROUNDED values (v_dot2_f32_f16 with ones): numerator (P*V) and normaliser see identical
-    // probabilities, so the truncation cancels in O = sum(p v) / sum(p).
+    // P = exp2(S*c - m) packed to fp16 pairs (round-toward-zero); the row sum is taken from the
+    // ROUNDED values (v_dot2_f32_f16 with ones) so numerator (P*V) and normaliser see identical
+    // probabilities and the truncation cancels in O = sum(p v) / sum(p).
     typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
     const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
     float lsum = 0.f;
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     l_run += lsum;
 
     // ---- O^T += V^T P^T ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
 #pragma unroll
@@ -221,12 +224,34 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- stage tile kt+1 into the other buffer (its last readers passed the previous barrier) ----
     if (kt + 1 < nt) {
-      store_tile((kt + 1) & 1);
+      store_tile(BUF ^ 1);
       if (kt + 2 < nt) load_tile(kt + 2);
     }
     __syncthreads();
+  };
+
+  load_tile(0);
+  store_tile(0);
+  if (nt > 1) load_tile(1);
+  __syncthreads();
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  const int nfull = p.lk / KT;  // tiles that need no mask
+  int kt = 0;
+  for (; kt + 1 < nfull; kt += 2) {  // buffer index == tile parity
+    tile(B0{}, std::false_type{}, kt);
+    tile(B1{}, std::false_type{}, kt + 1);
+  }
+  if (kt < nfull) {
+    tile(B0{}, std::false_type{}, kt);
+    ++kt;
+  }
+  if (kt < nt) {
+    if (kt & 1) tile(B1{}, std::true_type{}, kt);
+    else tile(B0{}, std::true_type{}, kt);
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
