@@ -170,20 +170,29 @@ def main():
 
     roofline = None
     if not args.no_roofline:
+        eng = net.engine()
+        was_graph, eng.use_graph = eng.use_graph, False  # events bracket individual launches: run eagerly
         ops.prof_enable(True)
         with torch.no_grad():
             step(min(Wm + K, num_sigmas - 2), x)
         prof = ops.prof_collect()
         ops.prof_enable(False)
+        eng.use_graph = was_graph
         mm = {k: prof[k] for k in ("gemm", "conv", "attention")}
         dom = max(mm, key=lambda k: mm[k]["ms"])
         d = mm[dom]
         ach = d["work"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
+        # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/traffic_from_pmc.py), not from here
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tfile) and (T, hw) == (21, 72):
+            traffic = json.load(open(tfile)).get(dom)
         roofline = {
             "bound": "mfma", "kernel": {"gemm": "gemm_kernel<plain>", "conv": "gemm_kernel<conv3x3>",
                                         "attention": "attn_kernel"}[dom],
             "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
+            "frac": ach / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic,
             "launches": d["launches"], "avg_launch_ms": d["ms"] / max(d["launches"], 1),
             "classes_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
             "classes_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)
@@ -220,6 +229,7 @@ def main():
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "novel_views_per_sec": value * (T - 1) / 50.0,
+            "hipgraph": bool(net.engine().use_graph),
             "config": {"workload": f"Seva 1.3B (1,263,968,004 params, random-init), one {T}-view window per GPU, "
                                    f"{hw * 8}x{hw * 8} px (latent {hw}x{hw}), CFG batch {2 * T}, Euler-EDM step, "
                                    "MultiviewCFG(1.2) cfg 2.0; novel_views_per_sec assumes 50 steps/window",
