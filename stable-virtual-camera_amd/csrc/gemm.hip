@@ -258,6 +258,12 @@ int launch(const GemmArgs& a, hipStream_t s) {
   // keeps its M-tile and walks as many N-tiles as that allows
   constexpr int kTargetBlocks = 1024;
   int chunks = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;
+  // SEVA_GEMM_CHUNKS=n (benchmark knob): at least n sibling workgroups share an M-tile's A panel
+  // concurrently on one XCD (L2 reuse) instead of one workgroup re-reading it per N-tile
+  if (const char* e = getenv("SEVA_GEMM_CHUNKS")) {
+    const int want = atoi(e);
+    if (want > chunks) chunks = want;
+  }
   if (chunks < 1) chunks = 1;
   if (chunks > args.tiles_n) chunks = args.tiles_n;
   args.n_chunks = chunks;
@@ -325,11 +331,12 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
     SEVA_REQUIRE(d->mode == 0, "geglu: plain mode only");
   }
   const bool narrow = d->N <= 32;
-  // kernel choice: SEVA_GEMM_CFG = 0 (128x128 two-stage), 1 (256x128x64 ring), 2 (256x256x32 ring)
+  // kernel choice: SEVA_GEMM_CFG = 0 (128x128 two-stage), 1/2/3 (ring variants), 4 (256x256 phased)
   // overrides the shape heuristic (benchmarking knob)
   int cfg = -1;
   if (const char* e = getenv("SEVA_GEMM_CFG")) cfg = atoi(e);
   if (cfg < 0) cfg = 0;
+  if (cfg == 4 && !narrow) return seva_gemm_phase_launch(a, d->mode, d->epilogue, s);
   if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
   if (d->epilogue == 1) return launch<128, 128, 0, 1>(a, s);
   if (d->mode == 0) return narrow ? launch<128, 32, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);

@@ -37,3 +37,5 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 
 // gemm_ring.hip: cfg 1 = 256x128x64 (3 stages), cfg 2 = 256x256x32 (4 stages), cfg 3 = 128x128x32 (4 stages)
 int seva_gemm_ring_launch(const GemmArgs& a, int mode, int epilogue, int cfg, hipStream_t s);
+// gemm_phase.hip: 256x256x64, two wave groups in anti-phase (cfg 4)
+int seva_gemm_phase_launch(const GemmArgs& a, int mode, int epilogue, hipStream_t s);
