@@ -256,7 +256,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
   args.tiles_n = (int)((a.N + BN - 1) / BN);
   // enough blocks for two full waves of the chip (256 CUs x 2 resident blocks), otherwise each block
   // keeps its M-tile and walks as many N-tiles as that allows
-  constexpr int kTargetBlocks = 1024;
+  constexpr int kTargetBlocks = BN == 64 ? 1536 : 1024;
   int chunks = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;
   // SEVA_GEMM_CHUNKS=n (benchmark knob): at least n sibling workgroups share an M-tile's A panel
   // concurrently on one XCD (L2 reuse) instead of one workgroup re-reading it per N-tile
@@ -339,6 +339,14 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (cfg == 4 && !narrow) return seva_gemm_phase_launch(a, d->mode, d->epilogue, s);
   if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
   if (d->epilogue == 1) return launch<128, 128, 0, 1>(a, s);
-  if (d->mode == 0) return narrow ? launch<128, 32, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
-  return narrow ? launch<128, 32, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
+  // N with a 64-column remainder (320, 960, 1920: every C = 320*k width): 128x64 tiles waste nothing
+  // where 128-wide tiles would idle up to 17 % of their MFMAs, and 48 KB of LDS allows 3 workgroups/CU
+  bool half_n = (d->N % 128) == 64 && d->N <= 320;
+  if (const char* e = getenv("SEVA_GEMM_BN64")) half_n = atoi(e) != 0 && (d->N % 64) == 0;
+  if (d->mode == 0) {
+    if (narrow) return launch<128, 32, 0, 0>(a, s);
+    return half_n ? launch<128, 64, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
+  }
+  if (narrow) return launch<128, 32, 1, 0>(a, s);
+  return half_n ? launch<128, 64, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
 }

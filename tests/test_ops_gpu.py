@@ -62,6 +62,29 @@ def test_gemm_exact_integers(dev, M, N, K):
     assert torch.equal(o16b.float(), (a @ w.T).half().float())
 
 
+@pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 4, 64), (777, 960, 640), (4097, 132, 192)])
+def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg):
+    """The ring (cfg 1-3) and phased (cfg 4) GEMM kernels are kept bit-exact with the default one."""
+    from seva import ops
+    os.environ["SEVA_GEMM_CFG"] = cfg
+    try:
+        a, w = _ints((M, K), -4, 4, dev, 1), _ints((N, K), -3, 3, dev, 2)
+        bias, res = _ints((N,), -5, 5, dev, 3), _ints((M, N), -9, 9, dev, 4)
+        o32 = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(a.half(), w.half(), bias=bias, residual=res, out_f32=o32)
+        assert torch.equal(o32, a @ w.T + bias + res)
+        x = _ints((2, 64, 9, 7), -3, 3, dev, 5)
+        wc = _ints((96, 64, 3, 3), -2, 2, dev, 6)
+        from seva._engine import pack_conv3x3
+        out = torch.full((2, 63, 96), float("nan"), device=dev)
+        ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(wc), out_f32=out)
+        ref = F.conv2d(x, wc, None, padding=1)
+        assert torch.equal(out.view(2, 9, 7, 96).permute(0, 3, 1, 2), ref)
+    finally:
+        os.environ.pop("SEVA_GEMM_CFG", None)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (2049, 1280, 1280)])
 def test_gemm_random(dev, M, N, K):
     from seva import ops
