@@ -256,17 +256,33 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (qrow < p.lq) {
-    half_t* const orow = obase + (int64_t)qrow * p.o_sl;
+  // ---- epilogue: O through LDS so that every global store is a full 128-byte row ----
+  // (per-lane 8-byte stores at a row stride touch 32 lines per instruction and amplify HBM writes;
+  // profiles/r01_traffic.json).  Each wave owns a 32-row x 128-byte image in the (now idle) K/V
+  // buffers; 16-byte chunk c of row r sits at c ^ (r & 7).
+  __syncthreads();  // every wave is done reading K/V tiles
+  char* const ow = smem + wave * (32 * 128);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        half4_t h;
+    for (int t = 0; t < 4; ++t) {
+      half4_t h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[db][4 * t + r] * inv);
-        *(half4_t*)(orow + 32 * db + 8 * t + 4 * hh) = h;
-      }
+      for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[db][4 * t + r] * inv);
+      const int d0 = 32 * db + 8 * t + 4 * hh;          // first of 4 consecutive head dims
+      const int chunk = d0 >> 3, piece = (d0 >> 2) & 1;  // 16-byte chunk, 8-byte half
+      *(half4_t*)(ow + qi * 128 + ((chunk ^ (qi & 7)) << 4) + (piece << 3)) = h;
+    }
+  // same wave reads back its own image: no workgroup barrier needed, only the LDS round trip
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  const int q0 = qb * (32 * NW) + wave * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + (lane >> 3), pchunk = lane & 7;
+    const uint4 v = *(const uint4*)(ow + row * 128 + (pchunk << 4));
+    const int lchunk = pchunk ^ (row & 7);
+    if (q0 + row < p.lq) *(uint4*)(obase + (int64_t)(q0 + row) * p.o_sl + lchunk * 8) = v;
   }
 }
 

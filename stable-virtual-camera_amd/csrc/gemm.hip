@@ -339,9 +339,10 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (cfg == 4 && !narrow) return seva_gemm_phase_launch(a, d->mode, d->epilogue, s);
   if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
   if (d->epilogue == 1) return launch<128, 128, 0, 1>(a, s);
-  // N with a 64-column remainder (320, 960, 1920: every C = 320*k width): 128x64 tiles waste nothing
-  // where 128-wide tiles would idle up to 17 % of their MFMAs, and 48 KB of LDS allows 3 workgroups/CU
-  bool half_n = (d->N % 128) == 64 && d->N <= 320;
+  // 128x64 tiles (no idle columns for N = 320, 3 workgroups/CU) measured 5-25 % SLOWER than 128x128
+  // on every shape of the step (profiles/r01_kbench_bn64.log): lower arithmetic intensity per LDS-DMA
+  // byte costs more than the 17 % of idle MFMA columns.  Kept as a benchmark knob only.
+  bool half_n = false;
   if (const char* e = getenv("SEVA_GEMM_BN64")) half_n = atoi(e) != 0 && (d->N % 64) == 0;
   if (d->mode == 0) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
