@@ -63,8 +63,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   const int wave = tid >> 6;
   const int qi = lane & 31, hh = lane >> 5;
 
-  // blockIdx.x = ((batch * heads) + head) * qblocks + qblock
-  int bid = blockIdx.x;
+  // logical id = ((batch * heads) + head) * qblocks + qblock.  Hardware deals blocks b, b+8, ... to
+  // one XCD; the bijective remap gives every XCD one contiguous run of logical ids, so the q-blocks
+  // of a (batch, head) pair -- which all stream the same K/V -- share one L2.
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
+    bid = ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+  }
   const int qb = bid % p.qblocks;
   bid /= p.qblocks;
   const int head = bid % p.heads;

@@ -110,7 +110,7 @@ def bench_attn(iters, quick):
         c3 = 3 * C
         regs = []
         if side in (72, 36, 18):
-            regs.append(("frame", dict(nb0=N, nb1=1, lq=hw, lk=hw, q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * C, 0, C)), 2))
+            regs.append(("frame", dict(nb0=N, nb1=1, lq=hw, lk=hw, q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * C, 0, C)), 5 if side == 72 else 2))
         if side in (36, 18, 9):
             regs.append(("joint", dict(nb0=2, nb1=1, lq=T * hw, lk=T * hw, q_strides=(T * hw * c3, 0, c3), k_strides=(T * hw * c3, 0, c3), o_strides=(T * hw * C, 0, C)), 3 if side != 9 else 1))
         regs.append(("temporal", dict(nb0=2, nb1=hw, lq=T, lk=T, q_strides=(T * hw * c3, c3, hw * c3), k_strides=(T * hw * c3, c3, hw * c3), o_strides=(T * hw * C, C, hw * C)), {72: 5, 36: 5, 18: 5, 9: 1}[side]))
