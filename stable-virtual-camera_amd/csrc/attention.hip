@@ -152,40 +152,42 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
       }
     }
     __builtin_amdgcn_s_setprio(0);
-    // Per 32-key half: mask, running max (deferred rescale), exp2/pack, then its share of
-    // O^T += V^T P^T.  Splitting per half lets the MFMA pipe work under the VALU: half 1's S MFMAs
-    // are still executing while half 0 is exponentiated, and half 0's P*V MFMAs run under half 1's.
-    typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
-    const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
+    if (MASKED) {  // keys >= lk exist only in the last tile
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (MASKED) {  // keys >= lk exist only in the last tile
+      for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
           if (key >= p.lk) sc[kb][r] = -1e30f;
         }
-      }
-      float mx = -1e30f;
+    }
+    // ---- online softmax, log2 domain, deferred rescale ----
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mxs = mx * c;  // c > 0
-      if (__any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
-        const float m_new = fmaxf(m_run, mxs);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * c;  // c > 0
+    if (__any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
+      const float m_new = fmaxf(m_run, mxs);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
-      }
-      // P = exp2(S*c - m) packed to fp16 pairs (round-toward-zero); the row sum is taken from the
-      // ROUNDED values (v_dot2_f32_f16 with ones) so numerator (P*V) and normaliser see identical
-      // probabilities and the truncation cancels in O = sum(p v) / sum(p).
-      float lsum = 0.f;
-      half8_t pf[2];
+        for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+    }
+    // P = exp2(S*c - m) packed to fp16 pairs (round-toward-zero); the row sum is taken from the
+    // ROUNDED values (v_dot2_f32_f16 with ones) so numerator (P*V) and normaliser see identical
+    // probabilities and the truncation cancels in O = sum(p v) / sum(p).
+    typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+    const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
+    float lsum = 0.f;
+    half8_t pf[KB][2];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         fp16x2_t pk[4];
@@ -196,14 +198,16 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
           pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
           lsum = __builtin_amdgcn_fdot2(pk[j], ones2, lsum, false);
         }
-        pf[s2] = __builtin_bit_cast(half8_t, pk);
+        pf[kb][s2] = __builtin_bit_cast(half8_t, pk);
       }
-      l_run += lsum;
+    l_run += lsum;
 
-      // ---- O^T += V^T P^T for these 32 keys ----
-      __builtin_amdgcn_s_setprio(1);
+    // ---- O^T += V^T P^T ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const int r0 = 32 * kb + 16 * s2 + 4 * hh;
@@ -222,11 +226,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
               vf[j] = *(const half_t*)(lds_v + row * 128 + (v_chunk_swz(row, d >> 3) << 4) + (d & 7) * 2);
             }
           }
-          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], acc_o[db], 0, 0, 0);
+          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], acc_o[db], 0, 0, 0);
         }
       }
-      __builtin_amdgcn_s_setprio(0);
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- stage tile kt+1 into the other buffer (its last readers passed the previous barrier) ----
     if (kt + 1 < nt) {
       store_tile(BUF ^ 1);
