@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     a_q[i] = q;
     int64_t m = m0 + row;
     if (m >= p.M) m = p.M - 1;
+    if (p.dbg & 4) m = row;
     if (MODE == 0) {
       a_ptr[i] = p.a + m * p.lda + q * 8;
       a_by[i] = a_bx[i] = 0;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       const int q = sp ^ ((row >> 1) & 7);
       int64_t n = (int64_t)tn * BN + row;
       if (n >= p.N) n = p.N - 1;
+      if (p.dbg & 4) n = row;
       b_ptr[i] = p.w + n * p.K + q * 8;
     }
   };
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     __syncthreads();  // stage 0 of this tile has landed (vmcnt(0) + barrier)
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      if (kt + 1 < nk && !(p.dbg & 1)) stage(cur ^ 1, kt + 1);
       const char* const ta = lds_a + cur * A_BYTES;
       const char* const tb = lds_b + cur * B_BYTES;
 #pragma unroll
@@ -149,11 +151,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         for (int i = 0; i < MI; ++i) af[i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bf[j] = *(const half8_t*)(tb + b_off[s] + j * (16 * 128));
+        if (!(p.dbg & 2)) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[j]));
+        }
       }
       __syncthreads();
     }
@@ -267,6 +276,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
   if (chunks < 1) chunks = 1;
   if (chunks > args.tiles_n) chunks = args.tiles_n;
   args.n_chunks = chunks;
+  args.dbg = 0;
+  if (const char* e = getenv("SEVA_GEMM_DBG")) args.dbg = atoi(e);
   const int64_t nb = (int64_t)args.tiles_m * chunks;
   if (nb <= 0 || nb > 0x7fffffff) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""GEMM ablation timing (default 128x128 kernel): SEVA_GEMM_DBG bits -> which resource bounds each shape."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
+import torch
+from seva import ops
+dev = torch.device("cuda:0")
+SHAPES = [(54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16"), (217728, 960, 320, "o16"), (13608, 1280, 5120, "o32res")]
+MODES = [(0, "full"), (1, "no loads"), (2, "no mfma"), (4, "same tile (L2)"), (5, "same tile+no loads"), (6, "same tile, no mfma")]
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for M, N, K, fl in SHAPES:
+    a = torch.randn(M, K, device=dev, dtype=torch.float16)
+    w = torch.randn(N, K, device=dev, dtype=torch.float16) * K ** -0.5
+    o16 = torch.empty(M, N, device=dev, dtype=torch.float16) if fl == "o16" else None
+    o32 = torch.empty(M, N, device=dev) if fl != "o16" else None
+    res = torch.randn(M, N, device=dev) if fl == "o32res" else None
+    line = f"{M}x{N}x{K} {fl:7s}"
+    for bits, name in MODES:
+        os.environ["SEVA_GEMM_DBG"] = str(bits)
+        us = timeit(lambda: ops.gemm(a, w, residual=res, out_f32=o32, out_f16=o16))
+        line += f" | {name}: {us:7.1f}us {2.0*M*N*K/us/1e6:6.0f}TF"
+    print(line, flush=True)
