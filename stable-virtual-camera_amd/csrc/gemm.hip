@@ -144,24 +144,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       if (kt + 1 < nk && !(p.dbg & 1)) stage(cur ^ 1, kt + 1);
       const char* const ta = lds_a + cur * A_BYTES;
       const char* const tb = lds_b + cur * B_BYTES;
+      // all 16 fragment reads of the K-tile are issued first: the second k-step's fragments land
+      // while the first k-step's MFMAs execute (the compiler waits with a counted lgkmcnt)
+      half8_t af[2][MI], bf[2][NJ];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        half8_t af[MI], bf[NJ];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
+        for (int i = 0; i < MI; ++i) af[s][i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[j] = *(const half8_t*)(tb + b_off[s] + j * (16 * 128));
+        for (int j = 0; j < NJ; ++j) bf[s][j] = *(const half8_t*)(tb + b_off[s] + j * (16 * 128));
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
         if (!(p.dbg & 2)) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
-          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[s][i]));
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[j]));
+          for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[s][j]));
         }
       }
       __syncthreads();
