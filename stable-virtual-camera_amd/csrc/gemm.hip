@@ -147,12 +147,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       // all 16 fragment reads of the K-tile are issued first: the second k-step's fragments land
       // while the first k-step's MFMAs execute (the compiler waits with a counted lgkmcnt)
       half8_t af[2][MI], bf[2][NJ];
+      if (!(p.dbg & 8) || kt == 0) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[s][i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
+          for (int i = 0; i < MI; ++i) af[s][i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[s][j] = *(const half8_t*)(tb + b_off[s] + j * (16 * 128));
+          for (int j = 0; j < NJ; ++j) bf[s][j] = *(const half8_t*)(tb + b_off[s] + j * (16 * 128));
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" : "=v"(af[s][i]));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bf[s][j]));
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[s][j]));
         }
       }
-      __syncthreads();
+      if (!(p.dbg & 16)) __syncthreads();
     }
     // both LDS buffers are free: start the next tile's first stage before the epilogue
     if (tn + 1 < tn_end) {
