@@ -29,6 +29,23 @@ static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_b
                                    0);
 }
 
+// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) treats the builtin as an LDS store that may alias
+// every later ds_read and protects it with `s_waitcnt vmcnt(0)`, which drains a multi-stage prefetch
+// ring at every K-tile.  Hidden in asm, the DMA is ordered only by the kernel's own counted
+// s_waitcnt vmcnt(N) + barrier.  M0 (LDS byte address of the wave's 1 KiB destination) is written in
+// the same statement that consumes it and restored afterwards (compiler-reserved register).
+static __device__ __forceinline__ unsigned lds_addr_u32(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+static __device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_wave_base)
+      : "memory");
+}
+
 // Bijective XCD-aware remap (blocks b, b+8, ... share an XCD): each XCD gets one contiguous run of
 // logical tiles, so the A row-panel it streams is fetched into that XCD's L2 once.
 static __device__ __forceinline__ int xcd_remap(int bid, int nb) {

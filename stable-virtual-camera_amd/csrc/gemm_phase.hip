@@ -65,6 +65,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
   // State is kept as 32-bit BYTE offsets against the uniform base pointers (the launcher checks that
   // every operand is < 4 GiB) to stay inside the 256-VGPR budget next to 128 accumulators.
   const int sr = lane >> 3, sp = lane & 7;
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));
   const char* const a_base = (const char*)p.a;
   const char* const w_base = (const char*)p.w;
   uint32_t a_off32[2][2];   // [ai][i]  MODE 0: row start + swizzled chunk; MODE 1: image start
@@ -106,11 +107,11 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
   // issue cursor over the flattened (N-tile, K-tile) sequence: the K-tile whose groups are being staged
   int i_tn = tn_begin, i_kt = 0;
   auto issue_a = [&](int buf, int x) {
-    char* const dst = smem + buf * BUF_BYTES + (x ? OFF_A1 : OFF_A0) + wave * 2048;
+    const unsigned dst = smem_base + buf * BUF_BYTES + (x ? OFF_A1 : OFF_A0) + wave * 2048;
     if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        glds16(a_base + (a_off32[x][i] + (uint32_t)(i_kt * (PB_BK * 2))), dst + i * 1024);
+        glds16_raw(a_base + (a_off32[x][i] + (uint32_t)(i_kt * (PB_BK * 2))), dst + i * 1024);
     } else {
       const int k0 = i_kt * PB_BK;
       const int tap = k0 / p.cin;
@@ -123,15 +124,15 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
         const bool ok = (iy >= 0) & (iy < eh) & (ix >= 0) & (ix < ew);
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
         const uint32_t off = a_off32[x][i] + (uint32_t)(((sy * p.iw + sx) * p.cin + ci0 + q_of(i) * 8) * 2);
-        glds16(ok ? (const void*)(a_base + off) : (const void*)g_zero_page, dst + i * 1024);
+        glds16_raw(ok ? (const void*)(a_base + off) : (const void*)g_zero_page, dst + i * 1024);
       }
     }
   };
   auto issue_b = [&](int buf, int x) {
-    char* const dst = smem + buf * BUF_BYTES + (x ? OFF_B1 : OFF_B0) + wave * 2048;
+    const unsigned dst = smem_base + buf * BUF_BYTES + (x ? OFF_B1 : OFF_B0) + wave * 2048;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      glds16(w_base + (b_off32[x][i] + (uint32_t)(i_kt * (PB_BK * 2))), dst + i * 1024);
+      glds16_raw(w_base + (b_off32[x][i] + (uint32_t)(i_kt * (PB_BK * 2))), dst + i * 1024);
   };
   auto advance_issue = [&]() {
     if (++i_kt == nk) {
@@ -243,6 +244,11 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
     c_kt = 0;
     const int64_t n0 = (int64_t)c_tn * PB_BN;
     ++c_tn;
+    // launder the lane id: everything the epilogue derives from it is recomputed here, once per
+    // tile, instead of being hoisted out of the K loop and held in (spilled) registers across it
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int fr = lane_e & 15, fg = lane_e >> 4;
     if (EPI == 0) {
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj) {

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
   const int total = (tn_end - tn_begin) * nk;
 
   // ---- staging state ----
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));
   const int sr = lane / LPR, sp = lane - sr * LPR;
   const half_t* a_ptr[A_PASSES];
   int a_by[A_PASSES], a_bx[A_PASSES], a_q[A_PASSES];
@@ -102,11 +103,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
   };
 
   auto stage = [&](int buf, int tn, int kt) {
-    char* const la = smem + buf * STAGE_BYTES + wave * A_PASSES * 1024;
-    char* const lb = smem + buf * STAGE_BYTES + A_BYTES + wave * B_PASSES * 1024;
+    const unsigned la = smem_base + buf * STAGE_BYTES + wave * A_PASSES * 1024;
+    const unsigned lb = smem_base + buf * STAGE_BYTES + A_BYTES + wave * B_PASSES * 1024;
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) glds16(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
+      for (int i = 0; i < A_PASSES; ++i) glds16_raw(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
     } else {
       const int k0 = kt * BK;
       const int tap = k0 / p.cin;
@@ -120,11 +121,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
         const half_t* src = p.a + a_img[i] + ((int64_t)sy * p.iw + sx) * p.cin + ci0 + a_q[i] * 8;
         const void* g = ok ? (const void*)src : (const void*)g_zero_page;
-        glds16(g, la + i * 1024);
+        glds16_raw(g, la + i * 1024);
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) glds16(b_ptr[i] + (int64_t)kt * BK, lb + i * 1024);
+    for (int i = 0; i < B_PASSES; ++i) glds16_raw(b_ptr[i] + (int64_t)kt * BK, lb + i * 1024);
   };
 
   // issue cursor over the flattened (tile, k) sequence
@@ -191,6 +192,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
     c_kt = 0;
     const int64_t n0 = (int64_t)c_tn * BN;
     ++c_tn;
+    // launder the lane id so epilogue address math is recomputed per tile, not held across the K loop
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int fr = lane_e & 15, fg = lane_e >> 4;
     if (EPI == 0) {
       f32x4 bj[NJ];
       int fj[NJ];
