@@ -33,6 +33,7 @@ struct AttnArgs {
   int64_t o_sb0, o_sb1, o_sl;
   int32_t nb1, heads, lq, lk, qblocks;
   float scale_log2;  // softmax scale * log2(e)
+  int32_t dbg;       // ablation bits (SEVA_ATTN_DBG; timing only): 1 no K/V reloads, 2 no softmax, 4 no P*V, 8 no Q*K
 };
 
 typedef short short8_t __attribute__((ext_vector_type(8)));
@@ -144,11 +145,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
       const int krow = 32 * kb + qi;
+      if (!(p.dbg & 8)) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const half8_t kf =
-            *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
-        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          const half8_t kf =
+              *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
+          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
+        }
+      } else {
+        asm volatile("" : "+v"(sc[kb]));
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -163,13 +168,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     }
     // ---- online softmax, log2 domain, deferred rescale ----
     float mx = -1e30f;
+    if (!(p.dbg & 2)) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+      for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    }
     const float mxs = mx * c;  // c > 0
-    if (__any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
+    if (!(p.dbg & 2) && __any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
       const float m_new = fmaxf(m_run, mxs);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -193,10 +200,16 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
         fp16x2_t pk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j], c, -m_run));
-          const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j + 1], c, -m_run));
+          float e0, e1;
+          if (!(p.dbg & 2)) {
+            e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j], c, -m_run));
+            e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j + 1], c, -m_run));
+          } else {
+            e0 = sc[kb][8 * s2 + 2 * j];
+            e1 = sc[kb][8 * s2 + 2 * j + 1];
+          }
           pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
-          lsum = __builtin_amdgcn_fdot2(pk[j], ones2, lsum, false);
+          if (!(p.dbg & 2)) lsum = __builtin_amdgcn_fdot2(pk[j], ones2, lsum, false);
         }
         pf[kb][s2] = __builtin_bit_cast(half8_t, pk);
       }
@@ -226,13 +239,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
               vf[j] = *(const half_t*)(lds_v + row * 128 + (v_chunk_swz(row, d >> 3) << 4) + (d & 7) * 2);
             }
           }
-          acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], acc_o[db], 0, 0, 0);
+          if (!(p.dbg & 4)) acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], acc_o[db], 0, 0, 0);
+          else asm volatile("" ::"v"(vf), "v"(pf[kb][s2]));
         }
       }
     }
     __builtin_amdgcn_s_setprio(0);
     // ---- stage tile kt+1 into the other buffer (its last readers passed the previous barrier) ----
-    if (kt + 1 < nt) {
+    if (kt + 1 < nt && !(p.dbg & 1)) {
       store_tile(BUF ^ 1);
       if (kt + 2 < nt) load_tile(kt + 2);
     }
@@ -329,6 +343,8 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   a.o_sb0 = d->o_sb0; a.o_sb1 = d->o_sb1; a.o_sl = d->o_sl;
   a.nb1 = d->nb1; a.heads = d->heads; a.lq = d->lq; a.lk = d->lk;
   a.scale_log2 = d->scale * 1.44269504088896340736f;
+  a.dbg = 0;
+  if (const char* e = getenv("SEVA_ATTN_DBG")) a.dbg = atoi(e);
   const int64_t batch = (int64_t)d->nb0 * d->nb1;
   const char* no_tr = getenv("SEVA_ATTN_NO_TR");  // debug knob: scalar LDS reads instead of tr_b16
   const bool use_tr = !(no_tr && no_tr[0] == '1');
