@@ -38,6 +38,21 @@ struct AttnArgs {
 
 typedef short short8_t __attribute__((ext_vector_type(8)));
 
+// LDS-DMA from inline asm (see gemm_common.h: hipcc would otherwise drain it with vmcnt(0) before
+// every ds_read); ordered only by the counted waits + barriers below.
+__device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_wave_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ half8_t tr_read_pair(const char* a0, const char* a1) {
   short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a0);
   short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a1);
@@ -50,14 +65,14 @@ __device__ __forceinline__ int k_chunk_swz(int row, int chunk) { return chunk ^ 
 
 template <int NW, int KT, bool USE_TR>
 __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
-  constexpr int NT = NW * 64;
   constexpr int KB = KT / 32;               // 32-key blocks per tile
-  constexpr int PASSES = (KT * 8) / NT;     // 16-byte chunks per thread per tile (K and V each)
-  static_assert((KT * 8) % NT == 0, "tile/threads mismatch");
 
-  // double-buffered K/V tiles: [buf][K tile | V tile]
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];
+  // 3-deep ring of K/V tiles filled by LDS-DMA two tiles ahead: [buf][K tile | V tile]
+  __shared__ __attribute__((aligned(16))) char smem[3 * 2 * KT * 128];
   constexpr int BUF_BYTES = 2 * KT * 128;
+  constexpr int IP = KT / 8 / NW;  // 8-row LDS-DMA instructions per wave per operand per tile
+  constexpr int G = 2 * IP;        // ... per wave per tile (K and V)
+  static_assert(KT % (8 * NW) == 0, "tile rows must split over the waves");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -103,27 +118,22 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   const float c = p.scale_log2;
 
   const int nt = (p.lk + KT - 1) / KT;
-  uint4 kreg[PASSES], vreg[PASSES];
-  const int lc = tid & 7, lr = tid >> 3;  // chunk / row of this thread's staging slot
-
-  auto load_tile = [&](int kt) {
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned smem_base =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  // lane (r = lane>>3, physical chunk = lane&7) of each 8-row wave-instruction; the swizzle is applied
+  // on the SOURCE chunk (the LDS image of an LDS-DMA is lane-linear)
+  const int sr = lane >> 3, sp = lane & 7;
+  auto issue_tile = [&](int kt, int buf) {
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      int key = kt * KT + lr + ps * (NT / 8);
+    for (int i = 0; i < IP; ++i) {
+      const int row = 8 * (wave_u * IP + i) + sr;
+      int key = kt * KT + row;
       if (key >= p.lk) key = p.lk - 1;
-      const int64_t off = (int64_t)key * p.k_sl + lc * 8;
-      kreg[ps] = *(const uint4*)(kbase + off);
-      vreg[ps] = *(const uint4*)(vbase + off);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* const lk_ = smem + buf * BUF_BYTES;
-    char* const lv_ = lk_ + KT * 128;
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int row = lr + ps * (NT / 8);
-      *(uint4*)(lk_ + row * 128 + (k_chunk_swz(row, lc) << 4)) = kreg[ps];
-      *(uint4*)(lv_ + row * 128 + (v_chunk_swz(row, lc) << 4)) = vreg[ps];
+      const int64_t roff = (int64_t)key * p.k_sl;
+      const unsigned dst = smem_base + buf * BUF_BYTES + 8 * (wave_u * IP + i) * 128;
+      glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
+      glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
     }
   };
 
@@ -136,6 +146,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     constexpr bool MASKED = decltype(masked_c)::value;
     const char* const lds_k = smem + BUF * BUF_BYTES;
     const char* const lds_v = lds_k + KT * 128;
+    // tile kt+2 -> buffer (kt+2)%3, last read in iteration kt-1 (every wave passed that barrier)
+    const bool more2 = kt + 2 < nt && !(p.dbg & 1);
+    if (more2) issue_tile(kt + 2, (BUF + 2) % 3);
 
     // ---- S^T = K Q^T ----
     f32x16 sc[KB];
@@ -246,32 +259,32 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     }
     __builtin_amdgcn_s_setprio(0);
     // ---- stage tile kt+1 into the other buffer (its last readers passed the previous barrier) ----
-    if (kt + 1 < nt && !(p.dbg & 1)) {
-      store_tile(BUF ^ 1);
-      if (kt + 2 < nt) load_tile(kt + 2);
-    }
+    // tile kt+1 (issued one iteration ago) must have landed; tile kt+2's G instructions may fly on
+    if (more2) wait_vm<G>();
+    else wait_vm<0>();
     __syncthreads();
   };
 
-  load_tile(0);
-  store_tile(0);
-  if (nt > 1) load_tile(1);
+  issue_tile(0, 0);
+  if (nt > 1) {
+    issue_tile(1, 1);
+    wait_vm<G>();
+  } else {
+    wait_vm<0>();
+  }
   __syncthreads();
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
+  using B2 = std::integral_constant<int, 2>;
   const int nfull = p.lk / KT;  // tiles that need no mask
-  int kt = 0;
-  for (; kt + 1 < nfull; kt += 2) {  // buffer index == tile parity
-    tile(B0{}, std::false_type{}, kt);
-    tile(B1{}, std::false_type{}, kt + 1);
-  }
-  if (kt < nfull) {
-    tile(B0{}, std::false_type{}, kt);
-    ++kt;
-  }
-  if (kt < nt) {
-    if (kt & 1) tile(B1{}, std::true_type{}, kt);
-    else tile(B0{}, std::true_type{}, kt);
+  auto run = [&](auto buf_c, int kt) {
+    if (kt < nfull) tile(buf_c, std::false_type{}, kt);
+    else tile(buf_c, std::true_type{}, kt);
+  };
+  for (int kt = 0; kt < nt; kt += 3) {  // buffer index == tile % 3
+    run(B0{}, kt);
+    if (kt + 1 < nt) run(B1{}, kt + 1);
+    if (kt + 2 < nt) run(B2{}, kt + 2);
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
