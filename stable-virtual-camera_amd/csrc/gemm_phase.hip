@@ -26,6 +26,8 @@
 // Operand layout, swizzle, MFMA orientation and epilogue contract are those of gemm.hip.
 #include "gemm_common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {
@@ -39,10 +41,14 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void bar() {
+__device__ __forceinline__ void bar_raw() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+#define bar()                       \
+  do {                              \
+    if (!(p.dbg & 16)) bar_raw();   \
+  } while (0)
 
 template <int MODE, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
@@ -163,12 +169,26 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
 
   half8_t af[4][2], bf[2][2];  // [i][s], [j][s]
   auto read_a = [&](const char* base) {
+    if (p.dbg & 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" : "=v"(af[i][s]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int s = 0; s < 2; ++s) af[i][s] = *(const half8_t*)(base + a_off[s] + i * 2048);
   };
   auto read_b = [&](const char* base) {
+    if (p.dbg & 8) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" : "=v"(bf[j][s]));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -176,6 +196,17 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
   };
   auto mfma_quadrant = [&](auto ai_c, auto bj_c) {
     constexpr int AI = decltype(ai_c)::value, BJ = decltype(bj_c)::value;
+    if (p.dbg & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" ::"v"(af[i][s]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" ::"v"(bf[j][s]));
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -205,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
   auto ktile = [&](auto buf_c, int g) {
     constexpr int BUF = decltype(buf_c)::value;
     const char* const cur = smem + BUF * BUF_BYTES;
-    const bool has_next = g + 1 < total;
+    const bool has_next = g + 1 < total && !(p.dbg & 1);
     // ---- phase 0: Q(a0,b0) ----
     if (has_next) issue_a(BUF ^ 1, 0);
     read_a(cur + OFF_A0);
@@ -358,6 +389,8 @@ int launch_phase(const GemmArgs& a, hipStream_t s) {
     return SEVA_ERR_UNSUPPORTED;
   }
   GemmArgs args = a;
+  args.dbg = 0;
+  if (const char* e = getenv("SEVA_GEMM_DBG")) args.dbg = atoi(e);
   args.tiles_m = (int)((a.M + PB_BM - 1) / PB_BM);
   args.tiles_n = (int)((a.N + PB_BN - 1) / PB_BN);
   int chunks = (512 + args.tiles_m - 1) / args.tiles_m;  // one workgroup per CU: aim at >= 2 rounds

@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
 import torch
 from seva import ops
 dev = torch.device("cuda:0")
-SHAPES = [(54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16"), (217728, 960, 320, "o16"), (13608, 1280, 5120, "o32res")]
-MODES = [(0, "full"), (1, "no loads"), (1 | 16, "no loads/barrier"), (1 | 8, "no loads/ldsread"), (1 | 8 | 16, "mfma only"), (2, "no mfma"), (2 | 8, "loads+barrier only")]
+SHAPES = [(54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16"), (217728, 960, 320, "o16"), (13608, 10240, 1280, "o16")]
+MODES = [(0, "full"), (1, "no loads"), (1 | 16, "no loads/barrier"), (1 | 8, "no loads/ldsread"), (1 | 8 | 16, "mfma only"), (2, "no mfma"), (2 | 8, "loads+barrier only"), (2 | 8 | 16, "loads only")]
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
