@@ -39,46 +39,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // Balanced static schedule: the grid has one workgroup per resident slot and workgroup b owns the
-  // contiguous range [b*T/G, (b+1)*T/G) of the linearised tile sequence (M-tile major, N-tile minor),
-  // so every workgroup gets T/G +- 1 tiles (no ragged last round) and mostly walks the N-tiles of one
-  // M-tile (A row-panel re-read from L2).  Neighbouring ranges sit on one XCD (xcd_remap).
-  const int64_t n_tiles = (int64_t)p.tiles_m * p.tiles_n;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t t_begin = n_tiles * lb / gridDim.x, t_end = n_tiles * (lb + 1) / gridDim.x;
-  if (t_begin >= t_end) return;
+  // block -> (M-tile, chunk of N-tiles).  A block walks its N-tiles itself: the A row-panel is
+  // fetched from HBM by the first tile and re-read from L2 by the others, instead of 8..80 sibling
+  // blocks all stalling on the same HBM miss for every K-tile.
+  const int work = xcd_remap(blockIdx.x, p.tiles_m * p.n_chunks);
+  const int tm = work / p.n_chunks, chunk = work - tm * p.n_chunks;
+  const int tn_begin = (int)((int64_t)chunk * p.tiles_n / p.n_chunks);
+  const int tn_end = (int)((int64_t)(chunk + 1) * p.tiles_n / p.n_chunks);
+  const int64_t m0 = (int64_t)tm * BM;
+
   // ---- staging state: lane (r = lane>>3, phys chunk = lane&7) of each 8-row wave-instruction ----
   const int sr = lane >> 3, sp = lane & 7;
   const half_t* a_ptr[A_PASSES];   // MODE 0: running source pointer
   int a_by[A_PASSES], a_bx[A_PASSES];  // MODE 1: top-left input coords (conv-input space)
   int64_t a_img[A_PASSES];             // MODE 1: element offset of image n
   int a_q[A_PASSES];
-  auto set_a_tile = [&](int tm) {
-    const int64_t m0 = (int64_t)tm * BM;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int row = wave * (BM / 4) + 8 * i + sr;  // row inside the tile
-      const int q = sp ^ ((row >> 1) & 7);           // logical 16-B chunk this lane fetches
-      a_q[i] = q;
-      int64_t m = m0 + row;
-      if (m >= p.M) m = p.M - 1;
-      if (p.dbg & 4) m = row;
-      if (MODE == 0) {
-        a_ptr[i] = p.a + m * p.lda + q * 8;
-        a_by[i] = a_bx[i] = 0;
-        a_img[i] = 0;
-      } else {
-        const int ohw = p.oh * p.ow;
-        const int img = (int)(m / ohw);
-        const int rem = (int)(m - (int64_t)img * ohw);
-        const int oy = rem / p.ow, ox = rem - oy * p.ow;
-        a_by[i] = oy * p.stride - 1;
-        a_bx[i] = ox * p.stride - 1;
-        a_img[i] = (int64_t)img * p.ih * p.iw * p.cin;
-        a_ptr[i] = nullptr;
-      }
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int row = wave * (BM / 4) + 8 * i + sr;  // row inside the tile
+    const int q = sp ^ ((row >> 1) & 7);           // logical 16-B chunk this lane fetches
+    a_q[i] = q;
+    int64_t m = m0 + row;
+    if (m >= p.M) m = p.M - 1;
+    if (p.dbg & 4) m = row;
+    if (MODE == 0) {
+      a_ptr[i] = p.a + m * p.lda + q * 8;
+      a_by[i] = a_bx[i] = 0;
+      a_img[i] = 0;
+    } else {
+      const int ohw = p.oh * p.ow;
+      const int img = (int)(m / ohw);
+      const int rem = (int)(m - (int64_t)img * ohw);
+      const int oy = rem / p.ow, ox = rem - oy * p.ow;
+      a_by[i] = oy * p.stride - 1;
+      a_bx[i] = ox * p.stride - 1;
+      a_img[i] = (int64_t)img * p.ih * p.iw * p.cin;
+      a_ptr[i] = nullptr;
     }
-  };
+  }
   const half_t* b_ptr[B_PASSES];
   auto set_b_tile = [&](int tn) {
 #pragma unroll
@@ -130,12 +128,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     b_off[s] = rb * 128 + (((4 * s + fg) ^ ((rb >> 1) & 7)) << 4);
   }
 
-  int tm = (int)(t_begin / p.tiles_n), tn = (int)(t_begin - (int64_t)tm * p.tiles_n);
-  set_a_tile(tm);
-  set_b_tile(tn);
+  set_b_tile(tn_begin);
   stage(0, 0);
-  for (int64_t t = t_begin; t < t_end; ++t) {
-    const int64_t m0 = (int64_t)tm * BM;
+  for (int tn = tn_begin; tn < tn_end; ++tn) {
     const int64_t n0 = (int64_t)tn * BN;
     f32x4 acc[MI][NJ];
 #pragma unroll
@@ -187,14 +182,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       if (!(p.dbg & 16)) __syncthreads();
     }
     // both LDS buffers are free: start the next tile's first stage before the epilogue
-    int tm_next = tm, tn_next = tn + 1;
-    if (tn_next == p.tiles_n) {
-      tn_next = 0;
-      ++tm_next;
-    }
-    if (t + 1 < t_end) {
-      if (tm_next != tm) set_a_tile(tm_next);
-      set_b_tile(tn_next);
+    if (tn + 1 < tn_end) {
+      set_b_tile(tn + 1);
       stage(0, 0);
     }
 
@@ -274,8 +263,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
       }
     }
-    tm = tm_next;
-    tn = tn_next;
   }
 }
 
@@ -291,13 +278,22 @@ int launch(const GemmArgs& a, hipStream_t s) {
   GemmArgs args = a;
   args.tiles_m = (int)((a.M + BM - 1) / BM);
   args.tiles_n = (int)((a.N + BN - 1) / BN);
-  // one workgroup per resident slot (256 CUs x workgroups that fit by LDS), never more than tiles
-  constexpr int kSlots = 256 * (BN == 64 ? 3 : (BN == 32 ? 4 : 2));
-  args.n_chunks = 1;
+  // enough blocks for two full waves of the chip (256 CUs x 2 resident blocks), otherwise each block
+  // keeps its M-tile and walks as many N-tiles as that allows
+  constexpr int kTargetBlocks = BN == 64 ? 1536 : 1024;
+  int chunks = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;
+  // SEVA_GEMM_CHUNKS=n (benchmark knob): at least n sibling workgroups share an M-tile's A panel
+  // concurrently on one XCD (L2 reuse) instead of one workgroup re-reading it per N-tile
+  if (const char* e = getenv("SEVA_GEMM_CHUNKS")) {
+    const int want = atoi(e);
+    if (want > chunks) chunks = want;
+  }
+  if (chunks < 1) chunks = 1;
+  if (chunks > args.tiles_n) chunks = args.tiles_n;
+  args.n_chunks = chunks;
   args.dbg = 0;
   if (const char* e = getenv("SEVA_GEMM_DBG")) args.dbg = atoi(e);
-  const int64_t n_tiles = (int64_t)args.tiles_m * args.tiles_n;
-  const int64_t nb = n_tiles < kSlots ? n_tiles : kSlots;
+  const int64_t nb = (int64_t)args.tiles_m * chunks;
   if (nb <= 0 || nb > 0x7fffffff) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
