@@ -301,8 +301,9 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   const int nthreads = cq <= GN_THREADS ? GN_THREADS : (cq >= GN_MAX_THREADS ? GN_MAX_THREADS : 64 * ((cq + 63) / 64));
   const int tpp = cq < nthreads ? cq : nthreads;
   const int plc = nthreads / tpp;
-  const int max_slabs = clampi(d->hw / plc, 1, GN_MAX_SLABS);
-  a.nslab_stats = clampi(2048 / d->n, 1, max_slabs);
+  // the statistics partition depends on the per-sample shape only (never on n): a sample's result
+  // is bit-identical whatever else is in the batch
+  a.nslab_stats = clampi(d->hw / (plc * 16), 1, GN_MAX_SLABS);
   const int plc_apply = cq <= GN_THREADS ? GN_THREADS / cq : 1;
   const int zchunks = cq <= GN_THREADS ? 1 : (cq + GN_THREADS - 1) / GN_THREADS;
   const int nslab_apply = clampi(4096 / (d->n * zchunks), 1, clampi(d->hw / (4 * plc_apply), 1, 1024));
