@@ -143,9 +143,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
       bsc[r] = dc ? p.dense_b[c] : 0.f;
       bsh[r] = dc ? p.dense_b[C + c] : 0.f;
 #pragma unroll
-      for (int j = 0; j < GN_MAX_DENSE; ++j) {
-        wsc[r][j] = (j < dc) ? p.dense_w[(int64_t)c * dc + j] : 0.f;
-        wsh[r][j] = (j < dc) ? p.dense_w[(int64_t)(C + c) * dc + j] : 0.f;
+      for (int j = 0; j < GN_MAX_DENSE; ++j) {  // branch-free: clamped index, then select
+        const int jj = j < dc ? j : (dc > 0 ? dc - 1 : 0);
+        const float w0 = DENSE ? p.dense_w[(int64_t)c * dc + jj] : 0.f;
+        const float w1 = DENSE ? p.dense_w[(int64_t)(C + c) * dc + jj] : 0.f;
+        wsc[r][j] = j < dc ? w0 : 0.f;
+        wsh[r][j] = j < dc ? w1 : 0.f;
       }
     }
     constexpr int U = DENSE ? 1 : 2;  // pixels in flight per thread (register budget)
@@ -306,7 +309,9 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   a.nslab_stats = clampi(d->hw / (plc * 16), 1, GN_MAX_SLABS);
   const int plc_apply = cq <= GN_THREADS ? GN_THREADS / cq : 1;
   const int zchunks = cq <= GN_THREADS ? 1 : (cq + GN_THREADS - 1) / GN_THREADS;
-  const int nslab_apply = clampi(4096 / (d->n * zchunks), 1, clampi(d->hw / (4 * plc_apply), 1, 1024));
+  // the modulated variant loads ~56 per-channel constants per thread: give each thread >= ~96 pixels
+  const int min_iter = d->dense ? 96 : 4;
+  const int nslab_apply = clampi(4096 / (d->n * zchunks), 1, clampi(d->hw / (min_iter * plc_apply), 1, 1024));
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)d->n * d->hw * C * (4.0 + 4.0 + 2.0);
   SevaProfScope prof(3, bytes, s);
