@@ -39,6 +39,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
+  // De-phase the workgroups: every workgroup does identical work per tile, so without this the whole
+  // chip alternates between "all in the MFMA main loop" and "all in the HBM-bound epilogue".  A
+  // pseudo-random start delay spreads the epilogues over time (stagger = sleep quantum, 0 = off).
+  if (p.stagger > 0) {
+    const unsigned h = (blockIdx.x * 2654435761u) >> 28;  // 0..15
+    for (unsigned i = 0; i < h * (unsigned)p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 1024 clocks each
+  }
+
   // block -> (M-tile, chunk of N-tiles).  A block walks its N-tiles itself: the A row-panel is
   // fetched from HBM by the first tile and re-read from L2 by the others, instead of 8..80 sibling
   // blocks all stalling on the same HBM miss for every K-tile.
@@ -210,12 +218,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         f32x4 v[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) v[j] = acc[i][j] + bj[j];
-        if (p.row_add) {
+        if (p.row_add && !(p.dbg & 32)) {
           const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
         }
-        if (p.residual) {
+        if (p.residual && !(p.dbg & 32)) {
           const float* rp = p.residual + mc * p.ldr;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
@@ -225,6 +233,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         for (int j = 0; j < NJ; ++j) {
           const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
           if (!row_ok || f >= p.N) continue;
+          if (p.dbg & 64) {
+            asm volatile("" ::"v"(v[j]));
+            continue;
+          }
           if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v[j];
           if (p.out_f16) {
             half4_t h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
@@ -293,6 +305,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
   args.n_chunks = chunks;
   args.dbg = 0;
   if (const char* e = getenv("SEVA_GEMM_DBG")) args.dbg = atoi(e);
+  args.stagger = 0;
+  if (const char* e = getenv("SEVA_GEMM_STAGGER")) args.stagger = atoi(e);
   const int64_t nb = (int64_t)args.tiles_m * chunks;
   if (nb <= 0 || nb > 0x7fffffff) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);

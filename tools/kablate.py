@@ -6,8 +6,9 @@ sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
 import torch
 from seva import ops
 dev = torch.device("cuda:0")
-SHAPES = [(54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16"), (217728, 960, 320, "o16"), (13608, 10240, 1280, "o16")]
-MODES = [(0, "full"), (1, "no loads"), (1 | 16, "no loads/barrier"), (1 | 8, "no loads/ldsread"), (1 | 8 | 16, "mfma only"), (2, "no mfma"), (2 | 8, "loads+barrier only"), (2 | 8 | 16, "loads only")]
+SHAPES = [(217728, 320, 320, "o32res"), (217728, 960, 320, "o16"), (217728, 320, 1280, "o32res"), (54432, 640, 640, "o32res"), (54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16")]
+MODES = [(0, "full")]
+STAG = [0, 1, 2, 4, 8]
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,8 +23,8 @@ for M, N, K, fl in SHAPES:
     o32 = torch.empty(M, N, device=dev) if fl != "o16" else None
     res = torch.randn(M, N, device=dev) if fl == "o32res" else None
     line = f"{M}x{N}x{K} {fl:7s}"
-    for bits, name in MODES:
-        os.environ["SEVA_GEMM_DBG"] = str(bits)
+    for st in STAG:
+        os.environ["SEVA_GEMM_STAGGER"] = str(st)
         us = timeit(lambda: ops.gemm(a, w, residual=res, out_f32=o32, out_f16=o16))
-        line += f" | {name}: {us:7.1f}us {2.0*M*N*K/us/1e6:6.0f}TF"
+        line += f" | st{st}: {us:7.1f}us {2.0*M*N*K/us/1e6:5.0f}TF"
     print(line, flush=True)
