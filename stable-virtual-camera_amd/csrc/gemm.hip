@@ -141,12 +141,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   for (int tn = tn_begin; tn < tn_end; ++tn) {
     const int64_t n0 = (int64_t)tn * BN;
     f32x4 acc[MI][NJ];
+    // The residual tile is loaded straight INTO the accumulators (the MFMAs add the product on top):
+    // its 16 loads per lane are in flight together with this tile's stage-0 DMA and cost no extra
+    // registers, instead of four load->wait->store round trips in the epilogue.  Addresses are
+    // clamped (M and N tails); the stores are guarded.
+    if (EPI == 0 && p.residual && !(p.dbg & 32)) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) {
+        int64_t m = m0 + wm * WM + 16 * i + fr;
+        if (m >= p.M) m = p.M - 1;
+        const float* rp = p.residual + m * p.ldr;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) {
+          int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+          if (f > p.N - 4) f = p.N - 4;
+          acc[i][j] = *(const f32x4*)(rp + f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    __syncthreads();  // stage 0 of this tile has landed (vmcnt(0) + barrier)
+    __syncthreads();  // stage 0 of this tile (and the residual) has landed (vmcnt(0) + barrier)
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       if (kt + 1 < nk && !(p.dbg & 1)) stage(cur ^ 1, kt + 1);
@@ -223,11 +242,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
         }
-        if (p.residual && !(p.dbg & 32)) {
-          const float* rp = p.residual + mc * p.ldr;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
-        }
         const bool row_ok = m < p.M;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -264,9 +278,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           if (fv >= p.N) continue;
           const f32x4 v = acc[i][j] + bv[j], g = acc[i][j + 2] + bg[j];
           const int64_t fo = (n0 + wn * WN) / 2 + 16 * j + 4 * fg;
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = v[r] * gelu_erf_f(g[r]);
+          const f32x4 o = geglu4(v, g);
           if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o;
           if (p.out_f16) {
             half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
@@ -290,15 +302,33 @@ int launch(const GemmArgs& a, hipStream_t s) {
   GemmArgs args = a;
   args.tiles_m = (int)((a.M + BM - 1) / BM);
   args.tiles_n = (int)((a.N + BN - 1) / BN);
-  // enough blocks for two full waves of the chip (256 CUs x 2 resident blocks), otherwise each block
-  // keeps its M-tile and walks as many N-tiles as that allows
+  // Schedule: an M-tile's N-tiles are split over `chunks` sibling workgroups that are adjacent in the
+  // XCD-remapped order, i.e. co-resident on one XCD: they stream the same A row-panel through that
+  // XCD's L2 at the same time.  One workgroup walking ALL N-tiles (the former default for big M)
+  // re-reads an 80..320 KB panel per N-tile while 512 such panels (40..160 MB) compete for 32 MB of
+  // L2.  Measured over every shape of a step (tools/ksweep_chunks.py, profiles/r01_ksweep_chunks.log):
+  // narrow outputs (<= 5 N-tiles) want one tile per workgroup, wide ones ~4 tiles per workgroup, and
+  // the split must be even (2,1,1,1 tiles is 30 % slower than 1,1,1,1,1).
   constexpr int kTargetBlocks = BN == 64 ? 1536 : 1024;
-  int chunks = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;
-  // SEVA_GEMM_CHUNKS=n (benchmark knob): at least n sibling workgroups share an M-tile's A panel
-  // concurrently on one XCD (L2 reuse) instead of one workgroup re-reading it per N-tile
+  const int base = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;  // >= two rounds of the chip
+  int chunks;
+  if (args.tiles_n <= 5) {
+    chunks = args.tiles_n;
+  } else {
+    int per = 0;
+    for (int t : {4, 5, 3, 2})
+      if (args.tiles_n % t == 0) { per = t; break; }
+    chunks = per ? args.tiles_n / per : (args.tiles_n + 3) / 4;
+  }
+  if (chunks < base) {
+    chunks = base;
+    for (int c = base; c <= 2 * base && c <= args.tiles_n; ++c)  // nearest even split above `base`
+      if (args.tiles_n % c == 0) { chunks = c; break; }
+  }
+  // SEVA_GEMM_CHUNKS=n (benchmark knob) overrides the heuristic
   if (const char* e = getenv("SEVA_GEMM_CHUNKS")) {
     const int want = atoi(e);
-    if (want > chunks) chunks = want;
+    if (want > 0) chunks = want;
   }
   if (chunks < 1) chunks = 1;
   if (chunks > args.tiles_n) chunks = args.tiles_n;

@@ -344,9 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
             const int64_t fv = n0 + wn * 64 + 16 * j + 4 * fg;
             const f32x4 v = acc[ai][i][0][j] + bv[j], gt = acc[ai][i][1][j] + bg[j];
             const int64_t fo = (n0 + wn * 64) / 2 + 16 * j + 4 * fg;
-            f32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = v[r] * gelu_erf_f(gt[r]);
+            const f32x4 o = geglu4(v, gt);
             if (m >= p.M || fv >= p.N) continue;
             if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o;
             if (p.out_f16) {

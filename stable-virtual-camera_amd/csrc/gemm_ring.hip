@@ -257,9 +257,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring_kernel(Gem
           if (fv >= p.N) continue;
           const f32x4 v = acc[i][j] + bv[j], gt = acc[i][j + 2] + bg[j];
           const int64_t fo = (n0 + wn * WN) / 2 + 16 * j + 4 * fg;
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = v[r] * gelu_erf_f(gt[r]);
+          const f32x4 o = geglu4(v, gt);
           if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o;
           if (p.out_f16) {
             half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};

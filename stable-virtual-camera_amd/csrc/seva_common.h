@@ -11,6 +11,7 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -68,4 +69,35 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   const float erf_abs = fmaf(-poly, e, 1.0f);                                  // erf(|x|/sqrt2)
   const float erf_signed = copysignf(erf_abs, x);
   return 0.5f * x * (1.0f + erf_signed);
+}
+
+// GEGLU epilogue value * gelu(gate) on four features at once, written on float2 so that hipcc emits
+// packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue slot).  erf by
+// Abramowitz & Stegun 7.1.28, erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16 (|error| <= 3e-7; measured
+// against float64 GELU over [-12, 12]: max abs error 8.8e-7): one quarter-rate op (rcp) per value
+// instead of two (rcp + exp2) and 14 packed full-rate ops per pair.  q^16 overflows to +inf for
+// |gate| > ~26, where rcp gives 0 and erf 1, the correct limit.
+__device__ __forceinline__ f32x2 geglu2(f32x2 v, f32x2 g) {
+  const auto c2 = [](float c) { return f32x2{c, c}; };
+  const f32x2 z = __builtin_elementwise_abs(g) * 0.70710678118654752440f;
+  f32x2 q = __builtin_elementwise_fma(z, c2(0.0000430638f), c2(0.0002765672f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0001520143f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0092705272f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0422820123f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0705230784f));
+  q = __builtin_elementwise_fma(q, z, c2(1.0f));
+  q = q * q;
+  q = q * q;
+  q = q * q;
+  q = q * q;
+  const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  const f32x2 e = __builtin_elementwise_fma(r, c2(-1.0f), c2(1.0f));  // erf(|g| / sqrt2)
+  const f32x2 es = {__builtin_copysignf(e[0], g[0]), __builtin_copysignf(e[1], g[1])};
+  const f32x2 h = g * 0.5f;
+  return v * __builtin_elementwise_fma(h, es, h);
+}
+__device__ __forceinline__ f32x4 geglu4(f32x4 v, f32x4 g) {
+  const f32x2 lo = geglu2(f32x2{v[0], v[1]}, f32x2{g[0], g[1]});
+  const f32x2 hi = geglu2(f32x2{v[2], v[3]}, f32x2{g[2], g[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }

@@ -14,7 +14,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
+# SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
+LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
 ABI_VERSION = 1
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")

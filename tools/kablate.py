@@ -8,7 +8,7 @@ from seva import ops
 dev = torch.device("cuda:0")
 SHAPES = [(217728, 320, 320, "o32res"), (217728, 960, 320, "o16"), (217728, 320, 1280, "o32res"), (54432, 640, 640, "o32res"), (54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16")]
 MODES = [(0, "full")]
-STAG = [0, 1, 2, 4, 8]
+STAG = [0]
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
