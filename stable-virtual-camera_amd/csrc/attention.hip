@@ -63,9 +63,13 @@ __device__ __forceinline__ half8_t tr_read_pair(const char* a0, const char* a1) 
 __device__ __forceinline__ int v_chunk_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
 __device__ __forceinline__ int k_chunk_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int NW, int KT, bool USE_TR>
+// DBGK: the ablation instantiation reads p.dbg at run time; the production one has no such branches
+// (they split the tile body into dozens of basic blocks and stop the scheduler interleaving
+// LDS reads, MFMAs and the softmax VALU work across them).
+template <int NW, int KT, bool USE_TR, bool DBGK>
 __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   constexpr int KB = KT / 32;               // 32-key blocks per tile
+  const int dbg = DBGK ? p.dbg : 0;
 
   // 3-deep ring of K/V tiles filled by LDS-DMA two tiles ahead: [buf][K tile | V tile]
   __shared__ __attribute__((aligned(16))) char smem[3 * 2 * KT * 128];
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     const char* const lds_k = smem + BUF * BUF_BYTES;
     const char* const lds_v = lds_k + KT * 128;
     // tile kt+2 -> buffer (kt+2)%3, last read in iteration kt-1 (every wave passed that barrier)
-    const bool more2 = kt + 2 < nt && !(p.dbg & 1);
+    const bool more2 = kt + 2 < nt && !(dbg & 1);
     if (more2) issue_tile(kt + 2, (BUF + 2) % 3);
 
     // ---- S^T = K Q^T ----
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
       const int krow = 32 * kb + qi;
-      if (!(p.dbg & 8)) {
+      if (!(dbg & 8)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const half8_t kf =
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     }
     // ---- online softmax, log2 domain, deferred rescale ----
     float mx = -1e30f;
-    if (!(p.dbg & 2)) {
+    if (!(dbg & 2)) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     }
     const float mxs = mx * c;  // c > 0
-    if (!(p.dbg & 2) && __any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
+    if (!(dbg & 2) && __any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
       const float m_new = fmaxf(m_run, mxs);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float e0, e1;
-          if (!(p.dbg & 2)) {
+          if (!(dbg & 2)) {
             e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j], c, -m_run));
             e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j + 1], c, -m_run));
           } else {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
             e1 = sc[kb][8 * s2 + 2 * j + 1];
           }
           pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
-          if (!(p.dbg & 2)) lsum = __builtin_amdgcn_fdot2(pk[j], ones2, lsum, false);
+          if (!(dbg & 2)) lsum = __builtin_amdgcn_fdot2(pk[j], ones2, lsum, false);
         }
         pf[kb][s2] = __builtin_bit_cast(half8_t, pk);
       }
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
               vf[j] = *(const half_t*)(lds_v + row * 128 + (v_chunk_swz(row, d >> 3) << 4) + (d & 7) * 2);
             }
           }
-          if (!(p.dbg & 4)) acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], acc_o[db], 0, 0, 0);
+          if (!(dbg & 4)) acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], acc_o[db], 0, 0, 0);
           else asm volatile("" ::"v"(vf), "v"(pf[kb][s2]));
         }
       }
@@ -328,10 +332,12 @@ int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr) {
     seva_set_error("attention: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  if (use_tr)
-    hipLaunchKernelGGL((attn_kernel<NW, KT, true>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
+  if (args.dbg)
+    hipLaunchKernelGGL((attn_kernel<NW, KT, true, true>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
+  else if (use_tr)
+    hipLaunchKernelGGL((attn_kernel<NW, KT, true, false>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
   else
-    hipLaunchKernelGGL((attn_kernel<NW, KT, false>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
+    hipLaunchKernelGGL((attn_kernel<NW, KT, false, false>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
   return seva_check_launch("attn_kernel");
 }
 

@@ -22,8 +22,10 @@ namespace {
 
 constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
 
-template <int BM, int BN, int MODE, int EPI>
+// DBGK: ablation instantiation (run-time p.dbg bits, SEVA_GEMM_DBG); the production one folds them away
+template <int BM, int BN, int MODE, int EPI, bool DBGK>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+  const int dbg = DBGK ? p.dbg : 0;
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave tile
   constexpr int MI = WM / 16, NJ = WN / 16;
   constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;  // 8-row wave-instructions per wave
@@ -39,10 +41,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // De-phase the workgroups: every workgroup does identical work per tile, so without this the whole
-  // chip alternates between "all in the MFMA main loop" and "all in the HBM-bound epilogue".  A
-  // pseudo-random start delay spreads the epilogues over time (stagger = sleep quantum, 0 = off).
-  if (p.stagger > 0) {
+  // Experiment knob (SEVA_GEMM_STAGGER): pseudo-random start delay to de-phase the workgroups'
+  // main loops and epilogues.  Measured: no gain at any quantum, so it lives in the ablation build only.
+  if (DBGK && p.stagger > 0) {
     const unsigned h = (blockIdx.x * 2654435761u) >> 28;  // 0..15
     for (unsigned i = 0; i < h * (unsigned)p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 1024 clocks each
   }
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     a_q[i] = q;
     int64_t m = m0 + row;
     if (m >= p.M) m = p.M - 1;
-    if (p.dbg & 4) m = row;
+    if (dbg & 4) m = row;
     if (MODE == 0) {
       a_ptr[i] = p.a + m * p.lda + q * 8;
       a_by[i] = a_bx[i] = 0;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       const int q = sp ^ ((row >> 1) & 7);
       int64_t n = (int64_t)tn * BN + row;
       if (n >= p.N) n = p.N - 1;
-      if (p.dbg & 4) n = row;
+      if (dbg & 4) n = row;
       b_ptr[i] = p.w + n * p.K + q * 8;
     }
   };
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // its 16 loads per lane are in flight together with this tile's stage-0 DMA and cost no extra
     // registers, instead of four load->wait->store round trips in the epilogue.  Addresses are
     // clamped (M and N tails); the stores are guarded.
-    if (EPI == 0 && p.residual && !(p.dbg & 32)) {
+    if (EPI == 0 && p.residual && !(dbg & 32)) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         int64_t m = m0 + wm * WM + 16 * i + fr;
@@ -168,13 +169,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     __syncthreads();  // stage 0 of this tile (and the residual) has landed (vmcnt(0) + barrier)
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk && !(p.dbg & 1)) stage(cur ^ 1, kt + 1);
+      if (kt + 1 < nk && !(dbg & 1)) stage(cur ^ 1, kt + 1);
       const char* const ta = lds_a + cur * A_BYTES;
       const char* const tb = lds_b + cur * B_BYTES;
       // all 16 fragment reads of the K-tile are issued first: the second k-step's fragments land
       // while the first k-step's MFMAs execute (the compiler waits with a counted lgkmcnt)
       half8_t af[2][MI], bf[2][NJ];
-      if (!(p.dbg & 8) || kt == 0) {
+      if (!(dbg & 8) || kt == 0) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        if (!(p.dbg & 2)) {
+        if (!(dbg & 2)) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[s][j]));
         }
       }
-      if (!(p.dbg & 16)) __syncthreads();
+      if (!(dbg & 16)) __syncthreads();
     }
     // both LDS buffers are free: start the next tile's first stage before the epilogue
     if (tn + 1 < tn_end) {
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         f32x4 v[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) v[j] = acc[i][j] + bj[j];
-        if (p.row_add && !(p.dbg & 32)) {
+        if (p.row_add && !(dbg & 32)) {
           const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         for (int j = 0; j < NJ; ++j) {
           const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
           if (!row_ok || f >= p.N) continue;
-          if (p.dbg & 64) {
+          if (dbg & 64) {
             asm volatile("" ::"v"(v[j]));
             continue;
           }
@@ -294,9 +295,11 @@ template <int BM, int BN, int MODE, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, MODE, EPI>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   GemmArgs args = a;
@@ -342,7 +345,10 @@ int launch(const GemmArgs& a, hipStream_t s) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, s, args);
+  if (args.dbg || args.stagger)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, true>), dim3((unsigned)nb), dim3(256), lds, s, args);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false>), dim3((unsigned)nb), dim3(256), lds, s, args);
   return seva_check_launch("gemm_kernel");
 }
 
