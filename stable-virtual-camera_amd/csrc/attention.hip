@@ -276,6 +276,12 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   } else {
     wait_vm<0>();
   }
+  // Retire the Q loads HERE as far as hipcc's wait-count bookkeeping is concerned.  Otherwise they are
+  // "possibly pending" at the loop header (merged over the back-edge), the compiler guards the first
+  // use of qf[0..3] in EVERY tile with s_waitcnt vmcnt(3)..vmcnt(0), and that vmcnt(0) drains the
+  // LDS-DMA ring (which it cannot see: the DMAs are issued from inline asm) once per tile.
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
   __syncthreads();
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;

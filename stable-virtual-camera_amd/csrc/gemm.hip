@@ -312,7 +312,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
   // L2.  Measured over every shape of a step (tools/ksweep_chunks.py, profiles/r01_ksweep_chunks.log):
   // narrow outputs (<= 5 N-tiles) want one tile per workgroup, wide ones ~4 tiles per workgroup, and
   // the split must be even (2,1,1,1 tiles is 30 % slower than 1,1,1,1,1).
-  constexpr int kTargetBlocks = BN == 64 ? 1536 : 1024;
+  constexpr int kTargetBlocks = 1024;
   const int base = (kTargetBlocks + args.tiles_m - 1) / args.tiles_m;  // >= two rounds of the chip
   int chunks;
   if (args.tiles_n <= 5) {
@@ -415,15 +415,16 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (cfg == 4 && !narrow) return seva_gemm_phase_launch(a, d->mode, d->epilogue, s);
   if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
   if (d->epilogue == 1) return launch<128, 128, 0, 1>(a, s);
-  // 128x64 tiles (no idle columns for N = 320, 3 workgroups/CU) measured 5-25 % SLOWER than 128x128
-  // on every shape of the step (profiles/r01_kbench_bn64.log): lower arithmetic intensity per LDS-DMA
-  // byte costs more than the 17 % of idle MFMA columns.  Kept as a benchmark knob only.
-  bool half_n = false;
-  if (const char* e = getenv("SEVA_GEMM_BN64")) half_n = atoi(e) != 0 && (d->N % 64) == 0;
+  // 128x160 tiles: every channel count of the network (320 .. 10240) is a multiple of 160, so no MFMA
+  // column is idle (N = 320: 2 tiles instead of 3 with the last half empty), and a tile needs 10 %
+  // fewer LDS-DMA bytes and fragment reads per FLOP than 128x128.  (128x64 tiles, tried earlier, were
+  // 5-25 % slower: profiles/r01_kbench_bn64.log.)  SEVA_GEMM_BN=128|160 forces the width (benchmark knob).
+  bool wide = d->N % 160 == 0;
+  if (const char* e = getenv("SEVA_GEMM_BN")) wide = atoi(e) == 160;
   if (d->mode == 0) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
-    return half_n ? launch<128, 64, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
+    return wide ? launch<128, 160, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
   }
   if (narrow) return launch<128, 32, 1, 0>(a, s);
-  return half_n ? launch<128, 64, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
+  return wide ? launch<128, 160, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
 }

@@ -47,11 +47,12 @@ __device__ __forceinline__ void bar_raw() {
 }
 #define bar()                       \
   do {                              \
-    if (!(p.dbg & 16)) bar_raw();   \
+    if (!(dbg & 16)) bar_raw();     \
   } while (0)
 
-template <int MODE, int EPI>
+template <int MODE, int EPI, bool DBGK>
 __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
+  const int dbg = DBGK ? p.dbg : 0;  // ablation bits only exist in the DBGK instantiation
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
 
   half8_t af[4][2], bf[2][2];  // [i][s], [j][s]
   auto read_a = [&](const char* base) {
-    if (p.dbg & 8) {
+    if (dbg & 8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
       for (int s = 0; s < 2; ++s) af[i][s] = *(const half8_t*)(base + a_off[s] + i * 2048);
   };
   auto read_b = [&](const char* base) {
-    if (p.dbg & 8) {
+    if (dbg & 8) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
   };
   auto mfma_quadrant = [&](auto ai_c, auto bj_c) {
     constexpr int AI = decltype(ai_c)::value, BJ = decltype(bj_c)::value;
-    if (p.dbg & 2) {
+    if (dbg & 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phase_kernel(GemmArgs p) {
   auto ktile = [&](auto buf_c, int g) {
     constexpr int BUF = decltype(buf_c)::value;
     const char* const cur = smem + BUF * BUF_BYTES;
-    const bool has_next = g + 1 < total && !(p.dbg & 1);
+    const bool has_next = g + 1 < total && !(dbg & 1);
     // ---- phase 0: Q(a0,b0) ----
     if (has_next) issue_a(BUF ^ 1, 0);
     read_a(cur + OFF_A0);
@@ -376,9 +377,11 @@ template <int MODE, int EPI>
 int launch_phase(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * BUF_BYTES;
   static bool attr_set = false;
-  auto kern = gemm_phase_kernel<MODE, EPI>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_phase_kernel<MODE, EPI, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_phase_kernel<MODE, EPI, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int64_t a_bytes = MODE == 0 ? a.M * a.lda * 2 : (int64_t)a.n * a.ih * a.iw * a.cin * 2;
@@ -400,7 +403,10 @@ int launch_phase(const GemmArgs& a, hipStream_t s) {
     seva_set_error("gemm_phase: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), lds, s, args);
+  if (args.dbg)
+    hipLaunchKernelGGL((gemm_phase_kernel<MODE, EPI, true>), dim3((unsigned)nb), dim3(512), lds, s, args);
+  else
+    hipLaunchKernelGGL((gemm_phase_kernel<MODE, EPI, false>), dim3((unsigned)nb), dim3(512), lds, s, args);
   return seva_check_launch("gemm_phase_kernel");
 }
 

@@ -36,7 +36,7 @@ def _rand(shape, dev, seed, scale=1.0):
 
 
 GEMM_SHAPES = [(256, 256, 128), (128, 128, 64), (300, 320, 320), (42, 1280, 320), (1000, 4, 64),
-               (777, 960, 640), (4097, 132, 192), (64, 36, 1024)]
+               (777, 960, 640), (4097, 132, 192), (64, 36, 1024), (513, 480, 128), (130, 160, 64)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -60,6 +60,22 @@ def test_gemm_exact_integers(dev, M, N, K):
     o16b = torch.empty((M, N), device=dev, dtype=torch.float16)
     ops.gemm(a.half(), w.half(), out_f16=o16b)
     assert torch.equal(o16b.float(), (a @ w.T).half().float())
+
+
+@pytest.mark.parametrize("bn", ["128", "160"])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (777, 132, 192), (257, 484, 64)])
+def test_gemm_tile_width_knob_exact(dev, M, N, K, bn, monkeypatch):
+    """Both tile widths (SEVA_GEMM_BN) on widths that leave ragged last tiles either way."""
+    from seva import ops
+    monkeypatch.setenv("SEVA_GEMM_BN", bn)
+    a = _ints((M, K), -4, 4, dev, 11)
+    w = _ints((N, K), -3, 3, dev, 12)
+    bias = _ints((N,), -5, 5, dev, 13)
+    res = _ints((M, N), -9, 9, dev, 14)
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a.half(), w.half(), bias=bias, residual=res, out_f32=o32)
+    torch.cuda.synchronize()
+    assert torch.equal(o32, a @ w.T + bias + res)
 
 
 @pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
