@@ -70,6 +70,11 @@ typedef struct seva_gemm_desc {
   int32_t mode;
   int32_t epilogue;
   int32_t n, ih, iw, cin, oh, ow, stride, upsample;
+  /* out[:, f] = (a @ w^T + bias)[:, f] * col_scale for f < col_scale_n (fp32, before the f16
+   * rounding); 0 columns = off.  Plain epilogue without residual / row_add only.  Used to fold the
+   * softmax scale * log2(e) into the q third of a fused QKV projection. */
+  float col_scale;
+  int32_t col_scale_n;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 
@@ -95,6 +100,9 @@ typedef struct seva_attn_desc {
   int32_t heads;
   int32_t lq, lk;
   float scale;
+  /* non-zero: q already holds q * scale * log2(e) (see seva_gemm_desc.col_scale); `scale` is ignored
+   * and the kernel evaluates softmax as exp2(q' . k - max) */
+  int32_t q_prescaled;
 } seva_attn_desc;
 int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream);
 

@@ -32,7 +32,7 @@ struct AttnArgs {
   int64_t k_sb0, k_sb1, k_sl;
   int64_t o_sb0, o_sb1, o_sl;
   int32_t nb1, heads, lq, lk, qblocks;
-  float scale_log2;  // softmax scale * log2(e)
+  float scale_log2;  // softmax scale * log2(e)  (unused when q is pre-scaled)
   int32_t dbg;       // ablation bits (SEVA_ATTN_DBG; timing only): 1 no K/V reloads, 2 no softmax, 4 no P*V, 8 no Q*K
 };
 
@@ -66,7 +66,10 @@ __device__ __forceinline__ int k_chunk_swz(int row, int chunk) { return chunk ^ 
 // DBGK: the ablation instantiation reads p.dbg at run time; the production one has no such branches
 // (they split the tile body into dozens of basic blocks and stop the scheduler interleaving
 // LDS reads, MFMAs and the softmax VALU work across them).
-template <int NW, int KT, bool USE_TR, bool DBGK>
+// PRE: q already carries scale*log2(e) (folded into the producing GEMM's fp32 epilogue).  The score
+// accumulators then START at -m_run (splat per key block: 16 moves instead of 32 v_fma), so
+// S^T = K Q^T comes out of the MFMA already in exp2's argument form.
+template <int NW, int KT, bool USE_TR, bool DBGK, bool PRE>
 __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   constexpr int KB = KT / 32;               // 32-key blocks per tile
   const int dbg = DBGK ? p.dbg : 0;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   // m_run is the exponent reference in the log2 domain (scaled scores); it may lag the true running
   // max by up to RESCALE_THR (deferred rescale), so probabilities are bounded by 2^RESCALE_THR.
   constexpr float RESCALE_THR = 8.0f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = PRE ? 0.f : -1e30f, l_run = 0.f;
   const float c = p.scale_log2;
 
   const int nt = (p.lk + KT - 1) / KT;
@@ -159,18 +162,24 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
       const int krow = 32 * kb + qi;
       if (!(dbg & 8)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const half8_t kf =
               *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
-          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
+          if (s == 0) {
+            f32x16 c0;
+            const float init = PRE ? -m_run : 0.f;  // PRE: splat(-m_run); else the literal 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c0[r] = init;
+            sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], c0, 0, 0, 0);
+          } else {
+            sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
+          }
         }
       } else {
-        asm volatile("" : "+v"(sc[kb]));
+        asm volatile("" : "=v"(sc[kb]));
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -192,6 +201,25 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     }
+    if (PRE) {
+      // scores are already relative to m_run: rescale when a row maximum exceeds the threshold, and
+      // unconditionally on the first tile (m_run starts at 0; nothing accumulated yet, so alpha = 1)
+      const bool first = kt == 0;
+      if (!(dbg & 2) && (first || __any(mx > RESCALE_THR))) {  // wave-uniform
+        const float delta = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+      }
+    } else {
     const float mxs = mx * c;  // c > 0
     if (!(dbg & 2) && __any(mxs > m_run + RESCALE_THR)) {  // wave-uniform
       const float m_new = fmaxf(m_run, mxs);
@@ -202,6 +230,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+    }
     }
     // P = exp2(S*c - m) packed to fp16 pairs (round-toward-zero); the row sum is taken from the
     // ROUNDED values (v_dot2_f32_f16 with ones) so numerator (P*V) and normaliser see identical
@@ -219,8 +248,13 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
         for (int j = 0; j < 4; ++j) {
           float e0, e1;
           if (!(dbg & 2)) {
-            e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j], c, -m_run));
-            e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j + 1], c, -m_run));
+            if (PRE) {
+              e0 = __builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * j]);
+              e1 = __builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * j + 1]);
+            } else {
+              e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j], c, -m_run));
+              e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][8 * s2 + 2 * j + 1], c, -m_run));
+            }
           } else {
             e0 = sc[kb][8 * s2 + 2 * j];
             e1 = sc[kb][8 * s2 + 2 * j + 1];
@@ -330,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 }
 
 template <int NW, int KT>
-int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr) {
+int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr, bool pre) {
   AttnArgs args = a;
   args.qblocks = (a.lq + 32 * NW - 1) / (32 * NW);
   const int64_t nb = batch * a.heads * args.qblocks;
@@ -338,12 +372,15 @@ int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr) {
     seva_set_error("attention: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  if (args.dbg)
-    hipLaunchKernelGGL((attn_kernel<NW, KT, true, true>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
-  else if (use_tr)
-    hipLaunchKernelGGL((attn_kernel<NW, KT, true, false>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
+  const dim3 grid((unsigned)nb), block(NW * 64);
+  if (args.dbg && !pre)
+    hipLaunchKernelGGL((attn_kernel<NW, KT, true, true, false>), grid, block, 0, s, args);
+  else if (!use_tr)
+    hipLaunchKernelGGL((attn_kernel<NW, KT, false, false, false>), grid, block, 0, s, args);
+  else if (pre)
+    hipLaunchKernelGGL((attn_kernel<NW, KT, true, false, true>), grid, block, 0, s, args);
   else
-    hipLaunchKernelGGL((attn_kernel<NW, KT, false, false>), dim3((unsigned)nb), dim3(NW * 64), 0, s, args);
+    hipLaunchKernelGGL((attn_kernel<NW, KT, true, false, false>), grid, block, 0, s, args);
   return seva_check_launch("attn_kernel");
 }
 
@@ -376,6 +413,8 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   hipStream_t s = (hipStream_t)stream;
   const double flops = 4.0 * (double)batch * d->heads * (double)d->lq * (double)d->lk * 64.0;
   SevaProfScope prof(2, flops, s);
-  if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr);
-  return launch<4, 64>(a, batch, s, use_tr);
+  const bool pre = d->q_prescaled != 0;
+  SEVA_REQUIRE(!pre || use_tr, "attention: q_prescaled is not available on the SEVA_ATTN_NO_TR debug path");
+  if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr, pre);
+  return launch<4, 64>(a, batch, s, use_tr, pre);
 }

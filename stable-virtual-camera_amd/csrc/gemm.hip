@@ -238,6 +238,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         f32x4 v[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) v[j] = acc[i][j] + bj[j];
+        if (p.col_scale_n > 0) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            if (n0 + wn * WN + 16 * j + 4 * fg < p.col_scale_n) v[j] *= p.col_scale;
+        }
         if (p.row_add && !(dbg & 32)) {
           const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
 #pragma unroll
@@ -382,6 +387,12 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   a.M = d->M; a.N = d->N; a.K = d->K;
   a.lda = d->lda; a.ldr = d->ldr; a.ldo32 = d->ldo32; a.ldo16 = d->ldo16;
   a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
+  a.col_scale = d->col_scale;
+  a.col_scale_n = d->col_scale_n;
+  SEVA_REQUIRE(d->col_scale_n >= 0 && d->col_scale_n % 4 == 0 && d->col_scale_n <= d->N,
+               "gemm: col_scale_n=%d invalid", d->col_scale_n);
+  SEVA_REQUIRE(d->col_scale_n == 0 || (!d->residual && !d->row_add && d->epilogue == 0 && d->N > 32),
+               "gemm: col_scale needs the plain epilogue without residual / row_add");
   a.ldra = d->ld_row_add > 0 ? d->ld_row_add : d->N;
   SEVA_REQUIRE(a.ldra % 4 == 0, "gemm: ld_row_add must be a multiple of 4");
   if (d->mode == 1) {

@@ -18,6 +18,8 @@ struct SevaGemmArgs {
   int32_t n, ih, iw, cin, oh, ow, stride, upsample;
   int32_t tiles_m, tiles_n;
   int32_t n_chunks;  // each block walks tiles_n / n_chunks consecutive N-tiles of one M-tile
+  float col_scale;   // features < col_scale_n are multiplied by col_scale (plain epilogue)
+  int32_t col_scale_n;
   int32_t stagger;   // start-delay quantum (s_sleep units of 64 clocks), 0 = none
   int32_t dbg;       // ablation bits (SEVA_GEMM_DBG, timing only, results wrong): 1 no loads after the
                      // first stage, 2 no MFMA, 4 every block loads tile (0,0)

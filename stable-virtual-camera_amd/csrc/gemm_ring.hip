@@ -303,6 +303,10 @@ int launch_ring(const GemmArgs& a, hipStream_t s, int blocks_per_cu = 1) {
 }  // namespace
 
 int seva_gemm_ring_launch(const GemmArgs& a, int mode, int epilogue, int cfg, hipStream_t s) {
+  if (a.col_scale_n > 0) {
+    seva_set_error("experimental gemm kernels do not implement col_scale");
+    return SEVA_ERR_UNSUPPORTED;
+  }
   if (cfg == 3) {  // 128x128x32, 4 stages (64 KB LDS -> 2 workgroups per CU), waves 2x2: 64x64 per wave
     if (epilogue == 1) return launch_ring<128, 128, 32, 4, 2, 2, 0, 1>(a, s, 2);
     return mode == 0 ? launch_ring<128, 128, 32, 4, 2, 2, 0, 0>(a, s, 2)

@@ -31,6 +31,8 @@ from ._arch import Layout
 from ._native import SevaNativeError, require_cuda
 
 F16, F32 = torch.float16, torch.float32
+# softmax scale of head dim 64 (reference transformer.py:66-72) times log2(e): exp(x) == exp2(x * log2 e)
+QK_SCALE_LOG2E = 0.125 * 1.4426950408889634
 CIN_PAD = 64  # conv A-operand channel granularity (one K-tile per tap)
 
 
@@ -253,21 +255,24 @@ class SevaEngine:
         W = self.W
         a = self._ln(x32, ln_pfx, rows, c)
         qkv = self._buf("qkv", (rows, 3 * c), F16)
-        ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv)
+        # softmax scale * log2(e) rides on the q third of the projection (fp32, before the single f16
+        # rounding), so the attention kernel exponentiates its MFMA output directly
+        ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)
         att = self._buf("att", (rows, c), F16)
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         c3 = 3 * c
         if regime == "frame":  # batch = frame, tokens = pixels
             ops.attention(q, k, v, att, nb0=n, nb1=1, heads=heads, lq=hw, lk=hw,
-                          q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * c, 0, c))
+                          q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * c, 0, c),
+                          q_prescaled=True)
         elif regime == "joint":  # batch = scene, tokens = (frame, pixel)
             ops.attention(q, k, v, att, nb0=n // T, nb1=1, heads=heads, lq=T * hw, lk=T * hw,
                           q_strides=(T * hw * c3, 0, c3), k_strides=(T * hw * c3, 0, c3),
-                          o_strides=(T * hw * c, 0, c))
+                          o_strides=(T * hw * c, 0, c), q_prescaled=True)
         else:  # temporal: batch = (scene, pixel), tokens = frames, read through strides
             ops.attention(q, k, v, att, nb0=n // T, nb1=hw, heads=heads, lq=T, lk=T,
                           q_strides=(T * hw * c3, c3, hw * c3), k_strides=(T * hw * c3, c3, hw * c3),
-                          o_strides=(T * hw * c, c, hw * c))
+                          o_strides=(T * hw * c, c, hw * c), q_prescaled=True)
         ops.gemm(att, W[at_pfx + ".out.w"], bias=W[at_pfx + ".out.b"], residual=residual,
                  row_add=row_add, rows_per_group=rpg, ld_row_add=ldra, out_f32=out_f32)
 

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
 
@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("mode", c_int32), ("epilogue", c_int32),
         ("n", c_int32), ("ih", c_int32), ("iw", c_int32), ("cin", c_int32),
         ("oh", c_int32), ("ow", c_int32), ("stride", c_int32), ("upsample", c_int32),
+        ("col_scale", c_float), ("col_scale_n", c_int32),
     ]
 
 
@@ -45,7 +46,7 @@ class AttnDesc(C.Structure):
         ("k_sb0", c_int64), ("k_sb1", c_int64), ("k_sl", c_int64),
         ("o_sb0", c_int64), ("o_sb1", c_int64), ("o_sl", c_int64),
         ("nb0", c_int32), ("nb1", c_int32), ("heads", c_int32),
-        ("lq", c_int32), ("lk", c_int32), ("scale", c_float),
+        ("lq", c_int32), ("lk", c_int32), ("scale", c_float), ("q_prescaled", c_int32),
     ]
 
 

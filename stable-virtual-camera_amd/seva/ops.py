@@ -34,8 +34,11 @@ def gemm(
     out_f32: torch.Tensor | None = None,
     out_f16: torch.Tensor | None = None,
     geglu: bool = False,
+    col_scale: float = 1.0,
+    col_scale_n: int = 0,
 ) -> None:
-    """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16)."""
+    """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16).
+    Output features < col_scale_n are multiplied by col_scale in fp32 (plain epilogue only)."""
     require_cuda(a, w)
     assert a.dtype == F16 and w.dtype == F16 and a.dim() == 2 and w.dim() == 2
     M, K = a.shape
@@ -51,6 +54,7 @@ def gemm(
     d.ldo16 = out_f16.stride(0) if out_f16 is not None else 0
     d.rows_per_group, d.ld_row_add = rows_per_group, ld_row_add
     d.mode, d.epilogue = 0, 1 if geglu else 0
+    d.col_scale, d.col_scale_n = col_scale, col_scale_n
     check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(a.device)), "seva_gemm_f16")
 
 
@@ -105,8 +109,10 @@ def attention(
     k_strides: tuple[int, int, int],
     o_strides: tuple[int, int, int],
     scale: float = 0.125,
+    q_prescaled: bool = False,
 ) -> None:
     """softmax(q k^T * scale) v per (batch, head), head dim 64 (seva_attention_f16).
+    q_prescaled: q already holds q * scale * log2(e) (gemm(col_scale=...)); `scale` is then ignored.
 
     q/k/v/out are f16 tensors (any views); strides are (batch-outer, batch-inner, token) in
     elements relative to the tensors' data pointers; head h sits at element offset 64*h."""
@@ -117,6 +123,7 @@ def attention(
     d.k_sb0, d.k_sb1, d.k_sl = k_strides
     d.o_sb0, d.o_sb1, d.o_sl = o_strides
     d.nb0, d.nb1, d.heads, d.lq, d.lk, d.scale = nb0, nb1, heads, lq, lk, scale
+    d.q_prescaled = 1 if q_prescaled else 0
     check(_lib().seva_attention_f16(C.byref(d), stream_ptr(q.device)), "seva_attention_f16")
 
 

@@ -33,10 +33,16 @@ def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, ou
 
 
 def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, residual=None,
-         out_f32=None, out_f16=None, geglu=False):
+         out_f32=None, out_f16=None, geglu=False, col_scale=1.0, col_scale_n=0):
     assert a.dtype == F16 and w.dtype == F16 and a.shape[1] % 64 == 0
     M, N = a.shape[0], w.shape[0]
     acc = a.float() @ w.float().T
+    if col_scale_n:
+        assert residual is None and row_add is None and not geglu
+        if bias is not None:
+            acc = acc + bias
+            bias = None
+        acc[:, :col_scale_n] *= col_scale
     _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu)
 
 
@@ -55,7 +61,10 @@ def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per
               out_f16, False)
 
 
-def attention(q, k, v, out, *, nb0, nb1, heads, lq, lk, q_strides, k_strides, o_strides, scale=0.125):
+def attention(q, k, v, out, *, nb0, nb1, heads, lq, lk, q_strides, k_strides, o_strides, scale=0.125,
+              q_prescaled=False):
+    if q_prescaled:  # q carries scale * log2(e): softmax base 2
+        scale = math.log(2.0)
     def view(t, st, L):
         return torch.as_strided(t, (nb0, nb1, L, heads, 64), (st[0], st[1], st[2], 64, 1), t.storage_offset())
     qv, kv, vv = view(q, q_strides, lq).float(), view(k, k_strides, lk).float(), view(v, k_strides, lk).float()

@@ -189,6 +189,80 @@ def test_attention_fused_qkv(dev, B, H, Lq, Lk, no_tr):
         os.environ.pop("SEVA_ATTN_NO_TR", None)
 
 
+QK_C = 0.125 * 1.4426950408889634
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 200, 200), (1, 1, 1701, 1701), (2, 3, 70, 5), (4, 2, 21, 21),
+                                       (1, 2, 33, 64), (2, 1, 500, 777)])
+@pytest.mark.parametrize("spike", [False, True])
+def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike):
+    """q already multiplied by scale*log2(e) (what the engine's QKV projection emits): the kernel starts
+    its score accumulators at -m_run and exponentiates the MFMA output directly.  `spike` plants, late in
+    the key sequence, keys that beat the running maximum by far more than the deferred-rescale threshold
+    (rescale branch), and shifts all logits of the first tile far below zero (first-tile reference)."""
+    from seva import ops
+    C = 64 * H
+    g = torch.Generator().manual_seed(31)
+    q = torch.randn((B, Lq, H, 64), generator=g)
+    k = torch.randn((B, Lk, H, 64), generator=g)
+    v = torch.randn((B, Lk, H, 64), generator=g)
+    if spike:
+        k[:, : min(64, Lk)] -= 3.0 * q[:, :1].mean(1, keepdim=True).sign()  # first tile: strongly negative-ish
+        if Lk > 70:
+            k[:, Lk - 3] = 6.0 * q[:, Lq // 2]  # a late key that dominates one query row
+            k[:, Lk // 2] = 4.0 * q[:, 0]
+    qs = (q * QK_C).half()
+    q16, k16, v16 = qs.to(dev).view(B, Lq, C), k.half().to(dev).view(B, Lk, C), v.half().to(dev).view(B, Lk, C)
+    out = torch.full((B, Lq, C), float("nan"), device=dev, dtype=torch.float16)
+    ops.attention(q16, k16, v16, out, nb0=B, nb1=1, heads=H, lq=Lq, lk=Lk, q_strides=(Lq * C, 0, C),
+                  k_strides=(Lk * C, 0, C), o_strides=(Lq * C, 0, C), q_prescaled=True)
+    # reference on exactly the operands the kernel sees: softmax base 2 of q' . k
+    qh = qs.double().transpose(1, 2)
+    kh = k.half().double().transpose(1, 2)
+    vh = v.half().double().transpose(1, 2)
+    att = torch.softmax(qh @ kh.transpose(-1, -2) * math.log(2.0), -1) @ vh
+    ref = att.transpose(1, 2).reshape(B, Lq, C)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out.cpu(), ref) < 2e-3
+
+
+def test_attention_prescaled_temporal(dev):
+    from seva import ops
+    B, T, S, H = 2, 21, 40, 2
+    C = 64 * H
+    qkv = _rand((B * T, S, 3 * C), dev, 12)
+    qkv[..., :C] *= QK_C
+    qkv = qkv.half()
+    out = torch.full((B * T, S, C), float("nan"), device=dev, dtype=torch.float16)
+    ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], out, nb0=B, nb1=S, heads=H,
+                  lq=T, lk=T, q_strides=(T * S * 3 * C, 3 * C, S * 3 * C),
+                  k_strides=(T * S * 3 * C, 3 * C, S * 3 * C), o_strides=(T * S * C, C, S * C), q_prescaled=True)
+    x = qkv.view(B, T, S, 3, H, 64).permute(3, 0, 2, 4, 1, 5).double()
+    ref = torch.softmax(x[0] @ x[1].transpose(-1, -2) * math.log(2.0), -1) @ x[2]
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(B * T, S, C)
+    assert rel_l2(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K,ns", [(300, 960, 320, 320), (130, 480, 64, 160), (257, 384, 128, 128)])
+def test_gemm_column_scale_exact(dev, M, N, K, ns):
+    """Features < col_scale_n are scaled in fp32 before the f16 rounding; the rest are untouched."""
+    from seva import ops
+    a = _ints((M, K), -4, 4, dev, 21)
+    w = _ints((N, K), -3, 3, dev, 22)
+    bias = _ints((N,), -5, 5, dev, 23)
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    o16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    ops.gemm(a.half(), w.half(), bias=bias, out_f32=o32, out_f16=o16, col_scale=0.375, col_scale_n=ns)
+    ref = a @ w.T + bias
+    ref[:, :ns] *= 0.375
+    torch.cuda.synchronize()
+    assert torch.equal(o32, ref)
+    assert torch.equal(o16.float(), ref.half().float())
+    with pytest.raises(Exception):
+        ops.gemm(a.half(), w.half(), residual=o32.clone(), out_f32=o32, col_scale=0.5, col_scale_n=ns)
+
+
+
 def test_attention_exact_uniform(dev):
     """All-equal scores -> output is the plain mean of V (exact in fp16 for integer V)."""
     from seva import ops

@@ -104,7 +104,12 @@ def bench_attn(iters, quick):
     tot = 0.0
     for side, C, H in LEVELS:
         hw = side * side
-        qkv = r16(N * hw, 3 * C)
+        pre = os.environ.get("KBENCH_ATTN_PRE", "1") != "0"  # engine path: q carries scale*log2(e)
+        qkv32 = torch.randn(N * hw, 3 * C, device=dev)
+        if pre:
+            qkv32[:, :C] *= 0.125 * 1.4426950408889634
+        qkv = qkv32.half()
+        del qkv32
         out = torch.empty(N * hw, C, device=dev, dtype=F16)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         c3 = 3 * C
@@ -115,7 +120,7 @@ def bench_attn(iters, quick):
             regs.append(("joint", dict(nb0=2, nb1=1, lq=T * hw, lk=T * hw, q_strides=(T * hw * c3, 0, c3), k_strides=(T * hw * c3, 0, c3), o_strides=(T * hw * C, 0, C)), 3 if side != 9 else 1))
         regs.append(("temporal", dict(nb0=2, nb1=hw, lq=T, lk=T, q_strides=(T * hw * c3, c3, hw * c3), k_strides=(T * hw * c3, c3, hw * c3), o_strides=(T * hw * C, C, hw * C)), {72: 5, 36: 5, 18: 5, 9: 1}[side]))
         for name, kw, calls in regs:
-            us = timeit(lambda: ops.attention(q, k, v, out, heads=H, **kw), iters)
+            us = timeit(lambda: ops.attention(q, k, v, out, heads=H, q_prescaled=pre, **kw), iters)
             flops = 4.0 * kw["nb0"] * kw["nb1"] * H * kw["lq"] * kw["lk"] * 64
             byts = N * hw * C * 2 * 4
             tot += us * calls / 1e3
