@@ -187,12 +187,13 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tfile) and (T, hw) == (21, 72):
-            traffic = json.load(open(tfile)).get(dom)
+            t = json.load(open(tfile)).get(dom)
+            traffic = t["bytes_per_launch"] if t else None  # HBM bytes per launch of the dominant class
         roofline = {
             "bound": "mfma", "kernel": {"gemm": "gemm_kernel<plain>", "conv": "gemm_kernel<conv3x3>",
                                         "attention": "attn_kernel"}[dom],
             "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic,
+            "frac": ach / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
             "launches": d["launches"], "avg_launch_ms": d["ms"] / max(d["launches"], 1),
             "classes_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
             "classes_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)

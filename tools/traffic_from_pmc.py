@@ -12,7 +12,11 @@ import json
 import os
 import sys
 
-CLASSES = {"gemm": "gemm_kernel<128, 128, 0, ", "conv": "gemm_kernel<128, 128, 1, ", "attention": "attn_kernel<4, 64"}
+import re
+
+# kernel names: gemm_kernel<BM, BN, MODE, EPI, DBG> (MODE 0 plain / 1 conv3x3), attn_kernel<NW, KT, ...>
+CLASSES = {"gemm": re.compile(r"gemm_kernel<128, (128|160), 0, "), "conv": re.compile(r"gemm_kernel<128, (128|160), 1, "),
+           "attention": re.compile(r"attn_kernel<4, 64")}
 
 
 def load(d, counter):
@@ -22,7 +26,7 @@ def load(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             for cls, pat in CLASSES.items():
-                if pat in r["Kernel_Name"]:
+                if pat.search(r["Kernel_Name"]):
                     e = tot.setdefault(cls, [0.0, 0])
                     e[0] += float(r["Counter_Value"]) * 1024.0
                     e[1] += 1
