@@ -23,14 +23,34 @@ namespace {
 constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
 
 // DBGK: ablation instantiation (run-time p.dbg bits, SEVA_GEMM_DBG); the production one folds them away
-template <int BM, int BN, int MODE, int EPI, bool DBGK>
+// PAIRED: weight-row -> MFMA-row assignment that gives a lane 8 consecutive features (f16-only outputs, GEGLU)
+template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int dbg = DBGK ? p.dbg : 0;
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave tile
   constexpr int MI = WM / 16, NJ = WN / 16;
   constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;  // 8-row wave-instructions per wave
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  static_assert(EPI == 0 || NJ == 4, "GEGLU epilogue needs a 64-wide wave tile");
+  static_assert(EPI == 0 || (NJ == 4 && PAIRED), "GEGLU epilogue needs a 64-wide wave tile, paired rows");
+  // Weight-row -> MFMA-row assignment.  D row r of a 16-row block lands in lane group fg = r >> 2, so
+  // with the natural order a lane owns 4 consecutive output features per block and the blocks of a
+  // lane are 16 features apart: 8-byte f16 stores, 32-byte fragments per token row.  Instead, blocks
+  // are taken in PAIRS (2p, 2p+1) over 32 weight rows and MFMA row r of block 2p+e reads tile row
+  //     32p + 8*(r>>2) + 4e + (r&3),
+  // so lane group fg owns features 32p + 8fg .. 8fg+7 across the pair: one 16-byte f16 store (two
+  // adjacent 16-byte f32 stores) per pair, i.e. 64 contiguous f16 bytes per token row and store.  Only
+  // the LDS read address changes; an odd last block (NJ = 5) keeps the natural order.  Measured: f16-out
+  // GEMMs 4-11 % faster, but f32 outputs 2-9 % SLOWER (each f32 store then writes 16-byte pieces with
+  // 16-byte holes), so PAIRED is only instantiated for f16-only outputs and the GEGLU epilogue.
+  // The B tile's chunk swizzle key follows the rows read together: pairs region bits {1,3,4} of the
+  // wave-relative row, natural region bits {1,2,3}.
+  constexpr int NJP = PAIRED ? (NJ & ~1) : 0;  // blocks handled in pairs
+  auto b_key = [](int row) {
+    const int rw = row % WN;  // wave-relative
+    return rw < NJP * 16 ? (((rw >> 1) & 1) | (((rw >> 3) & 3) << 1)) : ((rw >> 1) & 7);
+  };
+  // first output feature (relative to n0 + wn*WN) of block j for lane group fg
+  auto feat_of = [](int j, int fg) { return j < NJP ? 32 * (j >> 1) + 8 * fg + 4 * (j & 1) : 16 * j + 4 * fg; };
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [A buf0][A buf1][B buf0][B buf1]
@@ -91,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
       const int row = wave * (BN / 4) + 8 * i + sr;
-      const int q = sp ^ ((row >> 1) & 7);
+      const int q = sp ^ b_key(row);
       int64_t n = (int64_t)tn * BN + row;
       if (n >= p.N) n = p.N - 1;
       if (dbg & 4) n = row;
@@ -129,13 +149,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int nk = (int)(p.K / BK);
   // fragment-read byte offsets, hoisted: rows 16 apart share the swizzle term, so tile i / j of a
   // wave is `base + i*2048` (an immediate), not a recomputed XOR per ds_read
-  int a_off[2], b_off[2];
+  int a_off[2], b_off[2], b_off_last[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int ra = wm * WM + fr, rb = wn * WN + fr;
+    const int ra = wm * WM + fr;
     a_off[s] = ra * 128 + (((4 * s + fg) ^ ((ra >> 1) & 7)) << 4);
-    b_off[s] = rb * 128 + (((4 * s + fg) ^ ((rb >> 1) & 7)) << 4);
+    // paired blocks: block 2p+e adds (32p + 4e) rows, which leaves the key bits untouched
+    const int rb = wn * WN + (PAIRED ? 8 * (fr >> 2) + (fr & 3) : fr);
+    b_off[s] = rb * 128 + (((4 * s + fg) ^ b_key(rb)) << 4);
+    const int rl = wn * WN + 16 * (NJ - 1) + fr;  // odd last block, natural order
+    b_off_last[s] = rl * 128 + (((4 * s + fg) ^ b_key(rl)) << 4);
   }
+  auto b_frag_off = [&](int s, int j) {
+    if (!PAIRED) return b_off[s] + j * (16 * 128);
+    return j < NJP ? b_off[s] + (32 * (j >> 1) + 4 * (j & 1)) * 128 : b_off_last[s];
+  };
 
   set_b_tile(tn_begin);
   stage(0, 0);
@@ -154,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         const float* rp = p.residual + m * p.ldr;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+          int64_t f = n0 + wn * WN + feat_of(j, fg);
           if (f > p.N - 4) f = p.N - 4;
           acc[i][j] = *(const f32x4*)(rp + f);
         }
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) af[s][i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) bf[s][j] = *(const half8_t*)(tb + b_off[s] + j * (16 * 128));
+          for (int j = 0; j < NJ; ++j) bf[s][j] = *(const half8_t*)(tb + b_frag_off(s, j));
         }
       } else {
 #pragma unroll
@@ -223,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       int fj[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+        int64_t f = n0 + wn * WN + feat_of(j, fg);
         if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
         fj[j] = (int)f;
         bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         if (p.col_scale_n > 0) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            if (n0 + wn * WN + 16 * j + 4 * fg < p.col_scale_n) v[j] *= p.col_scale;
+            if (n0 + wn * WN + feat_of(j, fg) < p.col_scale_n) v[j] *= p.col_scale;
         }
         if (p.row_add && !(dbg & 32)) {
           const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
@@ -249,9 +277,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
         }
         const bool row_ok = m < p.M;
+        const bool pitch16_ok = (p.ldo16 & 7) == 0;  // 16-byte f16 stores need an 8-element row pitch
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+          const int64_t f = n0 + wn * WN + feat_of(j, fg);
           if (!row_ok || f >= p.N) continue;
           if (dbg & 64) {
             asm volatile("" ::"v"(v[j]));
@@ -259,51 +288,61 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           }
           if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v[j];
           if (p.out_f16) {
-            half4_t h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
-            *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+            if (j + 1 < NJP && (j & 1) == 0 && f + 8 <= p.N && pitch16_ok) {
+              // both halves of the pair in range: one 16-byte store of 8 consecutive features
+              half8_t h = {(half_t)v[j][0],     (half_t)v[j][1],     (half_t)v[j][2],     (half_t)v[j][3],
+                           (half_t)v[j + 1][0], (half_t)v[j + 1][1], (half_t)v[j + 1][2], (half_t)v[j + 1][3]};
+              *(half8_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+            } else if (j < NJP && (j & 1) == 1 && f + 4 <= p.N && pitch16_ok) {
+              // second half of a pair: already written by the 16-byte store above
+            } else {
+              half4_t h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
+              *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+            }
           }
         }
       }
     } else {
-      // wave's 64 weight rows = [16 v | 16 v | 16 g | 16 g] -> 32 output features
+      // wave's 64 weight rows = [32 v | 32 g] -> 32 output features; with the paired row assignment
+      // lane group fg owns value AND gate of features 8fg .. 8fg+7 (blocks 0,1 = v; 2,3 = g)
       f32x4 bv[2], bg[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int64_t fv = n0 + wn * WN + 16 * j + 4 * fg;  // interleaved-row index of the value
+      for (int e = 0; e < 2; ++e) {
+        int64_t fv = n0 + wn * WN + 8 * fg + 4 * e;  // interleaved-row index of the value
         if (fv > p.N - 36) fv = p.N - 36;
-        bv[j] = p.bias ? *(const f32x4*)(p.bias + fv) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bg[j] = p.bias ? *(const f32x4*)(p.bias + fv + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[e] = p.bias ? *(const f32x4*)(p.bias + fv) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bg[e] = p.bias ? *(const f32x4*)(p.bias + fv + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      const bool cols_ok = n0 + wn * WN < p.N;  // N % 64 == 0: a wave's 64 rows are all in or all out
+      const int64_t fo = (n0 + wn * WN) / 2 + 8 * fg;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int64_t m = m0 + wm * WM + 16 * i + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int64_t fv = n0 + wn * WN + 16 * j + 4 * fg;
-          if (fv >= p.N) continue;
-          const f32x4 v = acc[i][j] + bv[j], g = acc[i][j + 2] + bg[j];
-          const int64_t fo = (n0 + wn * WN) / 2 + 16 * j + 4 * fg;
-          const f32x4 o = geglu4(v, g);
-          if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o;
-          if (p.out_f16) {
-            half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-            *(half4_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
-          }
+        const f32x4 o0 = geglu4(acc[i][0] + bv[0], acc[i][2] + bg[0]);
+        const f32x4 o1 = geglu4(acc[i][1] + bv[1], acc[i][3] + bg[1]);
+        if (m >= p.M || !cols_ok) continue;
+        if (p.out_f32) {
+          *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o0;
+          *(f32x4*)(p.out_f32 + m * p.ldo32 + fo + 4) = o1;
+        }
+        if (p.out_f16) {
+          half8_t h = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3],
+                       (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
+          *(half8_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int MODE, int EPI>
-int launch(const GemmArgs& a, hipStream_t s) {
+template <int BM, int BN, int MODE, int EPI, bool PAIRED>
+int launch_p(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
@@ -351,10 +390,20 @@ int launch(const GemmArgs& a, hipStream_t s) {
     return SEVA_ERR_ARG;
   }
   if (args.dbg || args.stagger)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, true>), dim3((unsigned)nb), dim3(256), lds, s, args);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, true, PAIRED>), dim3((unsigned)nb), dim3(256), lds, s, args);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false>), dim3((unsigned)nb), dim3(256), lds, s, args);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED>), dim3((unsigned)nb), dim3(256), lds, s, args);
   return seva_check_launch("gemm_kernel");
+}
+
+template <int BM, int BN, int MODE, int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+  if (EPI == 1) return launch_p<BM, BN, MODE, EPI, true>(a, s);
+  if (EPI == 0 && MODE == 0 && BN >= 128 && a.out_f16 && !a.out_f32 && !a.residual) {
+    if constexpr (EPI == 0 && MODE == 0 && BN >= 128) return launch_p<BM, BN, MODE, EPI, true>(a, s);
+  }
+  if constexpr (EPI == 0) return launch_p<BM, BN, MODE, EPI, false>(a, s);
+  return SEVA_ERR_ARG;
 }
 
 }  // namespace
@@ -416,6 +465,7 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (d->epilogue == 1) {
     SEVA_REQUIRE(d->N % 64 == 0, "geglu: N=%lld not a multiple of 64", (long long)d->N);
     SEVA_REQUIRE(d->mode == 0, "geglu: plain mode only");
+    SEVA_REQUIRE(!d->out_f16 || d->ldo16 % 8 == 0, "geglu: f16 row pitch must be a multiple of 8");
   }
   const bool narrow = d->N <= 32;
   // kernel choice: SEVA_GEMM_CFG = 0 (128x128 two-stage), 1/2/3 (ring variants), 4 (256x256 phased)
