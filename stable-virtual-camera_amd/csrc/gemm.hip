@@ -22,6 +22,11 @@ namespace {
 
 constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
 
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // DBGK: ablation instantiation (run-time p.dbg bits, SEVA_GEMM_DBG); the production one folds them away
 // PAIRED: weight-row -> MFMA-row assignment that gives a lane 8 consecutive features (f16-only outputs, GEGLU)
 template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED>
@@ -123,8 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     char* const la = lds_a + buf * A_BYTES + wave * (BM / 4) * 128;
     char* const lb = lds_b + buf * B_BYTES + wave * (BN / 4) * 128;
     if (MODE == 0) {
+      if (!(dbg & 128)) {  // ablation bit 128: no A-operand staging (bound for an A-stationary kernel)
 #pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) glds16(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
+        for (int i = 0; i < A_PASSES; ++i) glds16(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
+      }
     } else {
       const int k0 = kt * BK;
       const int tap = k0 / p.cin;  // block-uniform: a K-tile never straddles taps (cin % 64 == 0)
@@ -143,6 +150,50 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) glds16(b_ptr[i] + (int64_t)kt * BK, lb + i * 1024);
+  };
+
+  // ASYNC schedule (f16-only outputs: fused QKV, GEGLU, 28 ms of a step).  The epilogue's stores used to
+  // be followed at once by the next tile's vmcnt(0): the store->ack latency (and, all workgroups
+  // storing together, the HBM write burst) was fully exposed: 33-37 % of the ds1 shapes' time
+  // (tools/kablate.py bits 64 / 256).  VMEM completes in issue order, so a wait for a load issued
+  // AFTER the stores also waits for the stores; therefore BOTH first stages of the next tile are
+  // issued BEFORE the epilogue and waited for with counted vmcnt(N) that leaves the S store
+  // instructions in flight; the first wait that covers them is the one at the end of K-tile 1.
+  // All LDS-DMA comes from inline asm here (hipcc would guard every ds_read behind a builtin DMA with
+  // vmcnt(0)), and the bias row travels with stage 0 into a per-wave 1 KiB LDS slot so that no
+  // compiler-visible global load (whose literal vmcnt would drain everything) remains in the loop.
+  constexpr bool ASYNC = PAIRED && !DBGK && MODE == 0;
+  constexpr int G = A_PASSES + B_PASSES;  // LDS-DMA instructions per wave per stage
+  constexpr int S_ST = EPI == 0 ? MI * (NJP / 2 + (NJ - NJP)) : MI;  // f16 store instructions per interior tile
+  const unsigned lds_base_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));
+  const unsigned bias_slot_u32 = lds_base_u32 + 2 * (A_BYTES + B_BYTES) + wave * 1024;
+  const char* const bias_slot = smem + 2 * (A_BYTES + B_BYTES) + wave * 1024;
+  auto stage_async = [&](int buf, int kt) {
+    const unsigned la = lds_base_u32 + buf * A_BYTES + wave * (BM / 4) * 128;
+    const unsigned lb = lds_base_u32 + 2 * A_BYTES + buf * B_BYTES + wave * (BN / 4) * 128;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) glds16_raw(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) glds16_raw(b_ptr[i] + (int64_t)kt * BK, lb + i * 1024);
+  };
+  auto stage_bias = [&](int tn) {  // lane L fetches bias[n0 + 4L .. +3] (clamped) into its wave's slot
+    int64_t f = (int64_t)tn * BN + 4 * lane;
+    if (f > p.N - 4) f = p.N - 4;
+    glds16_raw(p.bias + f, bias_slot_u32);
+  };
+  auto wait_counted = [&](bool stage1_flying, bool stores_flying) {
+    if (stage1_flying) {
+      if (stores_flying) wait_vm<G + S_ST>();
+      else wait_vm<G>();
+    } else {
+      if (stores_flying) wait_vm<S_ST>();
+      else wait_vm<0>();
+    }
+  };
+  auto barrier_raw = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
   const int fr = lane & 15, fg = lane >> 4;  // fragment row / k-group
@@ -166,7 +217,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   };
 
   set_b_tile(tn_begin);
-  stage(0, 0);
+  if (ASYNC) {
+    if (p.bias) stage_bias(tn_begin);
+    stage_async(0, 0);
+    if (nk > 1) stage_async(1, 1);
+  } else {
+    stage(0, 0);
+  }
+  bool stores_flying = false;  // ASYNC: the previous tile's S_ST stores may still be in flight
   for (int tn = tn_begin; tn < tn_end; ++tn) {
     const int64_t n0 = (int64_t)tn * BN;
     f32x4 acc[MI][NJ];
@@ -194,10 +252,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    __syncthreads();  // stage 0 of this tile (and the residual) has landed (vmcnt(0) + barrier)
+    if (ASYNC) {
+      wait_counted(nk > 1, stores_flying);  // stage 0 (+ bias) landed; stage 1 and old stores fly on
+      barrier_raw();
+    } else {
+      __syncthreads();  // stage 0 of this tile (and the residual) has landed (vmcnt(0) + barrier)
+    }
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk && !(dbg & 1)) stage(cur ^ 1, kt + 1);
+      if (ASYNC) {
+        if (kt >= 1 && kt + 1 < nk) stage_async(cur ^ 1, kt + 1);  // K-tile 1 was issued a tile ago
+      } else {
+        if (kt + 1 < nk && !(dbg & 1)) stage(cur ^ 1, kt + 1);
+      }
       const char* const ta = lds_a + cur * A_BYTES;
       const char* const tb = lds_b + cur * B_BYTES;
       // all 16 fragment reads of the K-tile are issued first: the second k-step's fragments land
@@ -235,13 +302,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[s][j]));
         }
       }
-      if (!(dbg & 16)) __syncthreads();
+      if (ASYNC) {
+        // K-tile kt+1 must have landed.  It was issued before the old stores when kt == 0 (they stay
+        // in flight), after them otherwise (vmcnt(0) then covers them, two K-tiles after their issue).
+        if (kt + 1 < nk) {
+          if (kt == 0) wait_counted(false, stores_flying);
+          else wait_vm<0>();
+        }
+        barrier_raw();
+      } else {
+        if (!(dbg & 16)) __syncthreads();
+      }
     }
-    // both LDS buffers are free: start the next tile's first stage before the epilogue
+    // bias of THIS tile out of the LDS slot before the next tile's stage 0 overwrites it
+    constexpr int NB = EPI == 0 ? NJ : 4;
+    f32x4 bias_r[NB];
+    if (ASYNC) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int idx = EPI == 0 ? wn * WN + feat_of(j, fg) : wn * WN + 8 * fg + 4 * (j & 1) + 32 * (j >> 1);
+        bias_r[j] = p.bias ? *(const f32x4*)(bias_slot + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // both LDS buffers are free: start the next tile's first stage(s) before the epilogue
     if (tn + 1 < tn_end) {
       set_b_tile(tn + 1);
-      stage(0, 0);
+      if (ASYNC) {
+        if (p.bias) stage_bias(tn + 1);
+        stage_async(0, 0);
+        if (nk > 1) stage_async(1, 1);
+      } else {
+        stage(0, 0);
+      }
     }
+    // ASYNC bookkeeping: S_ST is exact only for an interior tile (every guarded store executes) with
+    // 16-byte stores; anything else falls back to vmcnt(0)-strength waits (a smaller count is always safe)
+    stores_flying = ASYNC && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldo16 & 7) == 0 && !p.out_f32 &&
+                    tn + 1 < tn_end;
 
     // ---- epilogue: lane holds features f..f+3 (rows of D) of token m (column of D) ----
     if (EPI == 0) {
@@ -254,7 +352,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         int64_t f = n0 + wn * WN + feat_of(j, fg);
         if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
         fj[j] = (int)f;
-        bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ASYNC) bj[j] = bias_r[j];
+        else bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -277,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
         }
         const bool row_ok = m < p.M;
+        const int64_t ms = (dbg & 256) ? (m & 127) : m;  // ablation bit 256: stores land in an L2-resident region
         const bool pitch16_ok = (p.ldo16 & 7) == 0;  // 16-byte f16 stores need an 8-element row pitch
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -286,18 +386,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             asm volatile("" ::"v"(v[j]));
             continue;
           }
-          if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v[j];
+          if (p.out_f32) *(f32x4*)(p.out_f32 + ms * p.ldo32 + f) = v[j];
           if (p.out_f16) {
             if (j + 1 < NJP && (j & 1) == 0 && f + 8 <= p.N && pitch16_ok) {
               // both halves of the pair in range: one 16-byte store of 8 consecutive features
               half8_t h = {(half_t)v[j][0],     (half_t)v[j][1],     (half_t)v[j][2],     (half_t)v[j][3],
                            (half_t)v[j + 1][0], (half_t)v[j + 1][1], (half_t)v[j + 1][2], (half_t)v[j + 1][3]};
-              *(half8_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+              *(half8_t*)(p.out_f16 + ms * p.ldo16 + f) = h;
             } else if (j < NJP && (j & 1) == 1 && f + 4 <= p.N && pitch16_ok) {
               // second half of a pair: already written by the 16-byte store above
             } else {
               half4_t h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
-              *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+              *(half4_t*)(p.out_f16 + ms * p.ldo16 + f) = h;
             }
           }
         }
@@ -310,8 +410,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       for (int e = 0; e < 2; ++e) {
         int64_t fv = n0 + wn * WN + 8 * fg + 4 * e;  // interleaved-row index of the value
         if (fv > p.N - 36) fv = p.N - 36;
-        bv[e] = p.bias ? *(const f32x4*)(p.bias + fv) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bg[e] = p.bias ? *(const f32x4*)(p.bias + fv + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ASYNC) {
+          bv[e] = bias_r[e];
+          bg[e] = bias_r[2 + e];
+        } else {
+          bv[e] = p.bias ? *(const f32x4*)(p.bias + fv) : f32x4{0.f, 0.f, 0.f, 0.f};
+          bg[e] = p.bias ? *(const f32x4*)(p.bias + fv + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
       const bool cols_ok = n0 + wn * WN < p.N;  // N % 64 == 0: a wave's 64 rows are all in or all out
       const int64_t fo = (n0 + wn * WN) / 2 + 8 * fg;
@@ -337,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
 template <int BM, int BN, int MODE, int EPI, bool PAIRED>
 int launch_p(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds = 2 * (BM + BN) * 128 + (PAIRED ? 4096 : 0);  // + per-wave bias slots (ASYNC schedule)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED>,
@@ -398,12 +503,14 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int MODE, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
-  if (EPI == 1) return launch_p<BM, BN, MODE, EPI, true>(a, s);
-  if (EPI == 0 && MODE == 0 && BN >= 128 && a.out_f16 && !a.out_f32 && !a.residual) {
-    if constexpr (EPI == 0 && MODE == 0 && BN >= 128) return launch_p<BM, BN, MODE, EPI, true>(a, s);
+  if constexpr (EPI == 1) {
+    return launch_p<BM, BN, MODE, EPI, true>(a, s);
+  } else {
+    if constexpr (MODE == 0 && BN >= 128) {
+      if (a.out_f16 && !a.out_f32 && !a.residual) return launch_p<BM, BN, MODE, EPI, true>(a, s);
+    }
+    return launch_p<BM, BN, MODE, EPI, false>(a, s);
   }
-  if constexpr (EPI == 0) return launch_p<BM, BN, MODE, EPI, false>(a, s);
-  return SEVA_ERR_ARG;
 }
 
 }  // namespace

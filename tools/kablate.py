@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
 import torch
 from seva import ops
 dev = torch.device("cuda:0")
-SHAPES = [(217728, 320, 320, "o32res"), (217728, 960, 320, "o16"), (217728, 320, 1280, "o32res"), (54432, 640, 640, "o32res"), (54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16")]
-MODES = [(0, "full")]
-STAG = [0]
+SHAPES = [(217728, 960, 320, "o16"), (217728, 2560, 320, "o16"), (217728, 320, 320, "o32res"), (54432, 1920, 640, "o16")]
+# 1024 = dbg build with every bit off (its codegen differs from the production instantiation)
+MODES = [(0, "prod"), (1024, "dbg build"), (256, "stores to L2-resident rows"), (64, "no epi stores"), (128, "no A dma"), (128 | 256, "no A dma + L2 stores"), (128 | 64, "no A dma, no stores")]
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,8 +23,8 @@ for M, N, K, fl in SHAPES:
     o32 = torch.empty(M, N, device=dev) if fl != "o16" else None
     res = torch.randn(M, N, device=dev) if fl == "o32res" else None
     line = f"{M}x{N}x{K} {fl:7s}"
-    for st in STAG:
-        os.environ["SEVA_GEMM_STAGGER"] = str(st)
+    for bits, name in MODES:
+        os.environ["SEVA_GEMM_DBG"] = str(bits)
         us = timeit(lambda: ops.gemm(a, w, residual=res, out_f32=o32, out_f16=o16))
-        line += f" | st{st}: {us:7.1f}us {2.0*M*N*K/us/1e6:5.0f}TF"
+        line += f" | {name}: {us:6.1f}"
     print(line, flush=True)

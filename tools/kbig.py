@@ -13,7 +13,9 @@ def timeit(fn, iters=10):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-SH = [(4096, 4096, 4096), (8192, 8192, 8192), (13824, 10240, 1280), (13824, 1280, 5120), (54272, 5120, 640)]
+SH = [(217728, 960, 320), (217728, 2560, 320), (54432, 1920, 640), (54432, 5120, 640)]
+if os.environ.get("KBIG_SQUARE"):
+    SH = [(4096, 4096, 4096), (8192, 8192, 8192), (13824, 10240, 1280), (13824, 1280, 5120), (54272, 5120, 640)]
 CFG = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,4").split(",")]
 for M, N, K in SH:
     a = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.float16)
