@@ -29,14 +29,20 @@ __device__ __forceinline__ void wait_vm() {
 
 // DBGK: ablation instantiation (run-time p.dbg bits, SEVA_GEMM_DBG); the production one folds them away
 // PAIRED: weight-row -> MFMA-row assignment that gives a lane 8 consecutive features (f16-only outputs, GEGLU)
-template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED>
+// ASTAT (K <= 320, f16-only outputs): the A row-panel of the workgroup lives in REGISTERS.  Waves are
+// stacked 4x1 (32 rows x the full tile width each), every wave loads its 32 x K fragment set once
+// (<= 80 VGPRs) and only the weight tile is staged through LDS: 44 % fewer LDS-DMA bytes per FLOP for
+// the ds1 QKV / GEGLU projections, whose time was 15-23 % A re-staging (SEVA_GEMM_DBG=128).
+template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int dbg = DBGK ? p.dbg : 0;
-  constexpr int WM = BM / 2, WN = BN / 2;  // per-wave tile
+  constexpr int WM = ASTAT ? BM / 4 : BM / 2, WN = ASTAT ? BN : BN / 2;  // per-wave tile
   constexpr int MI = WM / 16, NJ = WN / 16;
-  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;  // 8-row wave-instructions per wave
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  static_assert(EPI == 0 || (NJ == 4 && PAIRED), "GEGLU epilogue needs a 64-wide wave tile, paired rows");
+  constexpr int A_PASSES = ASTAT ? 0 : BM / 32, B_PASSES = BN / 32;  // 8-row wave-instructions per wave
+  constexpr int A_BYTES = ASTAT ? 0 : BM * 128, B_BYTES = BN * 128;
+  constexpr int KS_A = 10;  // ASTAT: k-steps of 32 held in registers (K <= 320)
+  static_assert(!ASTAT || (PAIRED && MODE == 0 && !DBGK), "ASTAT rides on the ASYNC f16-only schedule");
+  static_assert(EPI == 0 || (NJ % 4 == 0 && PAIRED), "GEGLU epilogue needs 64-wide groups, paired rows");
   // Weight-row -> MFMA-row assignment.  D row r of a 16-row block lands in lane group fg = r >> 2, so
   // with the natural order a lane owns 4 consecutive output features per block and the blocks of a
   // lane are 16 features apart: 8-byte f16 stores, 32-byte fragments per token row.  Instead, blocks
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = ASTAT ? wave : wave >> 1, wn = ASTAT ? 0 : wave & 1;
 
   // Experiment knob (SEVA_GEMM_STAGGER): pseudo-random start delay to de-phase the workgroups'
   // main loops and epilogues.  Measured: no gain at any quantum, so it lives in the ablation build only.
@@ -84,10 +90,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   // ---- staging state: lane (r = lane>>3, phys chunk = lane&7) of each 8-row wave-instruction ----
   const int sr = lane >> 3, sp = lane & 7;
-  const half_t* a_ptr[A_PASSES];   // MODE 0: running source pointer
-  int a_by[A_PASSES], a_bx[A_PASSES];  // MODE 1: top-left input coords (conv-input space)
-  int64_t a_img[A_PASSES];             // MODE 1: element offset of image n
-  int a_q[A_PASSES];
+  constexpr int AP = A_PASSES > 0 ? A_PASSES : 1;  // (ASTAT stages no A tile)
+  const half_t* a_ptr[AP];         // MODE 0: running source pointer
+  int a_by[AP], a_bx[AP];          // MODE 1: top-left input coords (conv-input space)
+  int64_t a_img[AP];               // MODE 1: element offset of image n
+  int a_q[AP];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int row = wave * (BM / 4) + 8 * i + sr;  // row inside the tile
@@ -164,10 +171,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   // compiler-visible global load (whose literal vmcnt would drain everything) remains in the loop.
   constexpr bool ASYNC = PAIRED && !DBGK && MODE == 0;
   constexpr int G = A_PASSES + B_PASSES;  // LDS-DMA instructions per wave per stage
-  constexpr int S_ST = EPI == 0 ? MI * (NJP / 2 + (NJ - NJP)) : MI;  // f16 store instructions per interior tile
+  constexpr int S_ST = EPI == 0 ? MI * (NJP / 2 + (NJ - NJP)) : MI * (NJ / 4);  // f16 store instructions per interior tile
   const unsigned lds_base_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));
+  // bias slots: [parity][wave] x 1 KiB; only ASTAT alternates the parity per tile (it reads the bias lazily
+  // in the epilogue, while the next tile's bias is already in flight)
   const unsigned bias_slot_u32 = lds_base_u32 + 2 * (A_BYTES + B_BYTES) + wave * 1024;
   const char* const bias_slot = smem + 2 * (A_BYTES + B_BYTES) + wave * 1024;
+  auto bias_par = [&](int tn) { return ASTAT ? ((tn - tn_begin) & 1) * 4096 : 0; };
   auto stage_async = [&](int buf, int kt) {
     const unsigned la = lds_base_u32 + buf * A_BYTES + wave * (BM / 4) * 128;
     const unsigned lb = lds_base_u32 + 2 * A_BYTES + buf * B_BYTES + wave * (BN / 4) * 128;
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   auto stage_bias = [&](int tn) {  // lane L fetches bias[n0 + 4L .. +3] (clamped) into its wave's slot
     int64_t f = (int64_t)tn * BN + 4 * lane;
     if (f > p.N - 4) f = p.N - 4;
-    glds16_raw(p.bias + f, bias_slot_u32);
+    glds16_raw(p.bias + f, bias_slot_u32 + bias_par(tn));
   };
   auto wait_counted = [&](bool stage1_flying, bool stores_flying) {
     if (stage1_flying) {
@@ -215,6 +225,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     if (!PAIRED) return b_off[s] + j * (16 * 128);
     return j < NJP ? b_off[s] + (32 * (j >> 1) + 4 * (j & 1)) * 128 : b_off_last[s];
   };
+
+  // ASTAT: this wave's 32 x K A fragments, loaded once (MFMA B-operand layout: lane (fr, fg) holds
+  // row fr, k = 32*ks + 8*fg .. +7), then retired for hipcc's wait-count bookkeeping before the loop
+  half8_t areg[ASTAT ? MI : 1][ASTAT ? KS_A : 1];
+  if constexpr (ASTAT) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      int64_t m = m0 + wm * WM + 16 * i + fr;
+      if (m >= p.M) m = p.M - 1;
+      const half_t* ap = p.a + m * p.lda + 8 * fg;
+#pragma unroll
+      for (int ks = 0; ks < KS_A; ++ks) {
+        const int kk = 32 * ks < (int)p.K ? 32 * ks : 0;  // K < 320: unused k-steps re-read column 0
+        areg[i][ks] = *(const half8_t*)(ap + kk);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int ks = 0; ks < KS_A; ++ks) asm volatile("" : "+v"(areg[i][ks]));
+  }
 
   set_b_tile(tn_begin);
   if (ASYNC) {
@@ -258,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     } else {
       __syncthreads();  // stage 0 of this tile (and the residual) has landed (vmcnt(0) + barrier)
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    auto ktile = [&](int kt) {
       const int cur = kt & 1;
       if (ASYNC) {
         if (kt >= 1 && kt + 1 < nk) stage_async(cur ^ 1, kt + 1);  // K-tile 1 was issued a tile ago
@@ -269,6 +300,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       const char* const tb = lds_b + cur * B_BYTES;
       // all 16 fragment reads of the K-tile are issued first: the second k-step's fragments land
       // while the first k-step's MFMAs execute (the compiler waits with a counted lgkmcnt)
+      if constexpr (ASTAT) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          half8_t bfr[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bfr[j] = *(const half8_t*)(tb + b_frag_off(s2, j));
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], areg[i][2 * kt + s2], acc[i][j], 0, 0, 0);
+        }
+      } else {
       half8_t af[2][MI], bf[2][NJ];
       if (!(dbg & 8) || kt == 0) {
 #pragma unroll
@@ -302,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[s][j]));
         }
       }
+      }  // !ASTAT
       if (ASYNC) {
         // K-tile kt+1 must have landed.  It was issued before the old stores when kt == 0 (they stay
         // in flight), after them otherwise (vmcnt(0) then covers them, two K-tiles after their issue).
@@ -313,18 +358,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       } else {
         if (!(dbg & 16)) __syncthreads();
       }
+    };
+    if constexpr (ASTAT) {
+      // fully unrolled so that areg[][2*kt+s] is a static register index (a run-time index would
+      // send the array to scratch)
+#pragma unroll
+      for (int kt = 0; kt < KS_A / 2; ++kt)
+        if (kt < nk) ktile(kt);
+    } else {
+      for (int kt = 0; kt < nk; ++kt) ktile(kt);
     }
     // bias of THIS tile out of the LDS slot before the next tile's stage 0 overwrites it
-    constexpr int NB = EPI == 0 ? NJ : 4;
+    constexpr int NB = NJ;  // GEGLU: per 64-row group [v e=0, v e=1, g e=0, g e=1]
     f32x4 bias_r[NB];
-    if (ASYNC) {
+    if (ASYNC && !ASTAT) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int idx = EPI == 0 ? wn * WN + feat_of(j, fg) : wn * WN + 8 * fg + 4 * (j & 1) + 32 * (j >> 1);
+        const int idx = EPI == 0 ? wn * WN + feat_of(j, fg)
+                                 : wn * WN + 64 * (j >> 2) + 8 * fg + 4 * (j & 1) + 32 * ((j >> 1) & 1);
         bias_r[j] = p.bias ? *(const f32x4*)(bias_slot + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    const char* const bias_cur = bias_slot + bias_par(tn);
+    auto bias_idx = [&](int j) {  // tile-relative float index of block j's 4 bias values for this lane
+      return EPI == 0 ? wn * WN + feat_of(j, fg) : wn * WN + 64 * (j >> 2) + 8 * fg + 4 * (j & 1) + 32 * ((j >> 1) & 1);
+    };
+    auto bias_at = [&](int j) -> f32x4 {
+      if (!p.bias) return f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ASTAT) return *(const f32x4*)(bias_cur + bias_idx(j) * 4);
+      if (ASYNC) return bias_r[j];
+      // staged-A debug build: straight from global memory (GEGLU rows: value at +0, gate at +32 of each 64)
+      int64_t f = n0 + bias_idx(j);
+      if (f > p.N - 4) f = p.N - 4;
+      return *(const f32x4*)(p.bias + f);
+    };
     // both LDS buffers are free: start the next tile's first stage(s) before the epilogue
     if (tn + 1 < tn_end) {
       set_b_tile(tn + 1);
@@ -342,7 +410,53 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                     tn + 1 < tn_end;
 
     // ---- epilogue: lane holds features f..f+3 (rows of D) of token m (column of D) ----
-    if (EPI == 0) {
+    if constexpr (EPI == 0 && PAIRED) {
+      // f16-only output, a (pair of) block(s) at a time: at most two bias / addend vectors live
+      const bool pitch16_ok = (p.ldo16 & 7) == 0;  // 16-byte f16 stores need an 8-element row pitch
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int64_t m = m0 + wm * WM + 16 * i + fr;
+        const int64_t mc = m < p.M ? m : p.M - 1;
+        const bool row_ok = m < p.M;
+        const int64_t ms = (dbg & 256) ? (m & 127) : m;  // ablation bit 256: stores land in an L2-resident region
+        const float* const rp = p.row_add ? p.row_add + (mc / p.rows_per_group) * p.ldra : nullptr;
+#pragma unroll
+        for (int j = 0; j < NJ; j += (j < NJP ? 2 : 1)) {
+          const bool pair = j < NJP;
+          const int64_t f = n0 + wn * WN + feat_of(j, fg);
+          f32x4 v0 = acc[i][j] + bias_at(j);
+          f32x4 v1 = pair ? acc[i][pair ? j + 1 : j] + bias_at(pair ? j + 1 : j) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.col_scale_n > 0) {
+            if (f < p.col_scale_n) v0 *= p.col_scale;
+            if (f + 4 < p.col_scale_n) v1 *= p.col_scale;
+          }
+          if (rp && !(dbg & 32)) {
+            int64_t f0 = f, f1 = f + 4;
+            if (f0 > p.N - 4) f0 = p.N - 4;
+            if (f1 > p.N - 4) f1 = p.N - 4;
+            v0 += *(const f32x4*)(rp + f0);
+            if (pair) v1 += *(const f32x4*)(rp + f1);
+          }
+          if (!row_ok || f >= p.N) continue;
+          if (dbg & 64) {
+            asm volatile("" ::"v"(v0), "v"(v1));
+            continue;
+          }
+          if (pair && f + 8 <= p.N && pitch16_ok) {
+            half8_t h = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3],
+                         (half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+            *(half8_t*)(p.out_f16 + ms * p.ldo16 + f) = h;
+          } else {
+            half4_t h0 = {(half_t)v0[0], (half_t)v0[1], (half_t)v0[2], (half_t)v0[3]};
+            *(half4_t*)(p.out_f16 + ms * p.ldo16 + f) = h0;
+            if (pair && f + 4 < p.N) {
+              half4_t h1 = {(half_t)v1[0], (half_t)v1[1], (half_t)v1[2], (half_t)v1[3]};
+              *(half4_t*)(p.out_f16 + ms * p.ldo16 + f + 4) = h1;
+            }
+          }
+        }
+      }
+    } else if constexpr (EPI == 0) {
       // per 16-row block: issue every addend load (bias is hoisted; row_add and residual = 8
       // independent 16-byte loads in flight), then add + store
       f32x4 bj[NJ];
@@ -352,8 +466,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         int64_t f = n0 + wn * WN + feat_of(j, fg);
         if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
         fj[j] = (int)f;
-        if (ASYNC) bj[j] = bias_r[j];
-        else bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -403,52 +516,51 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
       }
     } else {
-      // wave's 64 weight rows = [32 v | 32 g] -> 32 output features; with the paired row assignment
-      // lane group fg owns value AND gate of features 8fg .. 8fg+7 (blocks 0,1 = v; 2,3 = g)
-      f32x4 bv[2], bg[2];
+      // every 64 weight rows of the wave = [32 v | 32 g] -> 32 output features; with the paired row
+      // assignment lane group fg owns value AND gate of features 8fg .. 8fg+7 (blocks 4q,4q+1 = v; 4q+2,4q+3 = g)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        int64_t fv = n0 + wn * WN + 8 * fg + 4 * e;  // interleaved-row index of the value
-        if (fv > p.N - 36) fv = p.N - 36;
-        if (ASYNC) {
-          bv[e] = bias_r[e];
-          bg[e] = bias_r[2 + e];
-        } else {
-          bv[e] = p.bias ? *(const f32x4*)(p.bias + fv) : f32x4{0.f, 0.f, 0.f, 0.f};
-          bg[e] = p.bias ? *(const f32x4*)(p.bias + fv + 32) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      const bool cols_ok = n0 + wn * WN < p.N;  // N % 64 == 0: a wave's 64 rows are all in or all out
-      const int64_t fo = (n0 + wn * WN) / 2 + 8 * fg;
+      for (int gq = 0; gq < NJ / 4; ++gq) {
+        const int base = wn * WN + 64 * gq;  // tile-relative first weight row of the group
+        f32x4 bv[2], bg[2];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int64_t m = m0 + wm * WM + 16 * i + fr;
-        const f32x4 o0 = geglu4(acc[i][0] + bv[0], acc[i][2] + bg[0]);
-        const f32x4 o1 = geglu4(acc[i][1] + bv[1], acc[i][3] + bg[1]);
-        if (m >= p.M || !cols_ok) continue;
-        if (p.out_f32) {
-          *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o0;
-          *(f32x4*)(p.out_f32 + m * p.ldo32 + fo + 4) = o1;
+        for (int e = 0; e < 2; ++e) {
+          bv[e] = bias_at(4 * gq + e);
+          bg[e] = bias_at(4 * gq + 2 + e);
         }
-        if (p.out_f16) {
-          half8_t h = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3],
-                       (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
-          *(half8_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
+        const bool cols_ok = n0 + base < p.N;  // N % 64 == 0: a group's 64 rows are all in or all out
+        const int64_t fo = (n0 + base) / 2 + 8 * fg;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int64_t m = m0 + wm * WM + 16 * i + fr;
+          const f32x4 o0 = geglu4(acc[i][4 * gq + 0] + bv[0], acc[i][4 * gq + 2] + bg[0]);
+          const f32x4 o1 = geglu4(acc[i][4 * gq + 1] + bv[1], acc[i][4 * gq + 3] + bg[1]);
+          if (m >= p.M || !cols_ok) continue;
+          if (p.out_f32) {
+            *(f32x4*)(p.out_f32 + m * p.ldo32 + fo) = o0;
+            *(f32x4*)(p.out_f32 + m * p.ldo32 + fo + 4) = o1;
+          }
+          if (p.out_f16) {
+            half8_t h = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3],
+                         (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
+            *(half8_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
+          }
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int MODE, int EPI, bool PAIRED>
+template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false>
 int launch_p(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 2 * (BM + BN) * 128 + (PAIRED ? 4096 : 0);  // + per-wave bias slots (ASYNC schedule)
+  constexpr int lds = 2 * ((ASTAT ? 0 : BM) + BN) * 128 + (ASTAT ? 8192 : PAIRED ? 4096 : 0);  // + bias slots (ASYNC)
+  constexpr bool DBG_BUILD = !ASTAT;  // the ablation instantiation only exists for the staged-A kernels
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (DBG_BUILD)
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   GemmArgs args = a;
@@ -494,20 +606,30 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  if (args.dbg || args.stagger)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, true, PAIRED>), dim3((unsigned)nb), dim3(256), lds, s, args);
-  else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED>), dim3((unsigned)nb), dim3(256), lds, s, args);
+  if constexpr (DBG_BUILD) {
+    if (args.dbg || args.stagger) {
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, true, PAIRED, false>), dim3((unsigned)nb), dim3(256), lds, s, args);
+      return seva_check_launch("gemm_kernel");
+    }
+  }
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT>), dim3((unsigned)nb), dim3(256), lds, s, args);
   return seva_check_launch("gemm_kernel");
 }
 
 template <int BM, int BN, int MODE, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
+  // SEVA_GEMM_ASTAT=0 disables the A-in-registers variant (benchmark knob)
+  static const bool astat_on = [] { const char* e = getenv("SEVA_GEMM_ASTAT"); return !(e && e[0] == '0'); }();
+  const bool dbg_run = getenv("SEVA_GEMM_DBG") || getenv("SEVA_GEMM_STAGGER");
   if constexpr (EPI == 1) {
+    if (astat_on && !dbg_run && a.K <= 320 && a.out_f16 && !a.out_f32) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
     return launch_p<BM, BN, MODE, EPI, true>(a, s);
   } else {
     if constexpr (MODE == 0 && BN >= 128) {
-      if (a.out_f16 && !a.out_f32 && !a.residual) return launch_p<BM, BN, MODE, EPI, true>(a, s);
+      if (a.out_f16 && !a.out_f32 && !a.residual) {
+        if (astat_on && !dbg_run && a.K <= 320) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
+        return launch_p<BM, BN, MODE, EPI, true>(a, s);
+      }
     }
     return launch_p<BM, BN, MODE, EPI, false>(a, s);
   }
