@@ -619,7 +619,8 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
 template <int BM, int BN, int MODE, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
   // SEVA_GEMM_ASTAT=0 disables the A-in-registers variant (benchmark knob)
-  static const bool astat_on = [] { const char* e = getenv("SEVA_GEMM_ASTAT"); return !(e && e[0] == '0'); }();
+  const char* const astat_env = getenv("SEVA_GEMM_ASTAT");
+  const bool astat_on = !(astat_env && astat_env[0] == '0');
   const bool dbg_run = getenv("SEVA_GEMM_DBG") || getenv("SEVA_GEMM_STAGGER");
   if constexpr (EPI == 1) {
     if (astat_on && !dbg_run && a.K <= 320 && a.out_f16 && !a.out_f32) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
