@@ -363,6 +363,253 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-chain variant for long sequences (engine path: pre-scaled q, tr-reads): a wave owns 64 query
+// rows as two independent 32-row chains A and B at 2 waves/SIMD.  Within one tile the order is
+//   QK(A) | QK(B) + softmax(A) | PV(A) + softmax(B) | PV(B)
+// so that one chain's exp/cvt VALU work issues in the shadow of the other chain's MFMAs inside ONE
+// instruction stream (the three-waves-per-SIMD kernel above relies on the hardware interleaving
+// separate waves, which barrier and wait stalls defeat about 40 % of the time).  Same LDS ring,
+// operand layouts, online-softmax arithmetic and rounding as attn_kernel<4, 64, true, false, true>.
+template <int KT>
+__global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
+  constexpr int NW = 4, QB = 2, KB = KT / 32;
+  __shared__ __attribute__((aligned(16))) char smem[3 * 2 * KT * 128];
+  constexpr int BUF_BYTES = 2 * KT * 128;
+  constexpr int IP = KT / 8 / NW;
+  constexpr int G = 2 * IP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int qi = lane & 31, hh = lane >> 5;
+
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
+    bid = ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+  }
+  const int qb = bid % p.qblocks;
+  bid /= p.qblocks;
+  const int head = bid % p.heads;
+  const int batch = bid / p.heads;
+  const int b0 = batch / p.nb1, b1 = batch - b0 * p.nb1;
+
+  const half_t* const qbase = p.q + b0 * p.q_sb0 + b1 * p.q_sb1 + head * 64;
+  const half_t* const kbase = p.k + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
+  const half_t* const vbase = p.v + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
+  half_t* const obase = p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64;
+
+  half8_t qf[QB][4];
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    const int qrow = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c + qi;
+    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[c][s] = *(const half8_t*)(qbase + (int64_t)qrow_c * p.q_sl + 16 * s + 8 * hh);
+  }
+
+  f32x16 acc_o[QB][2];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    m_run[c] = 0.f;
+    l_run[c] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[c][d][r] = 0.f;
+  }
+  constexpr float RESCALE_THR = 8.0f;
+
+  const int nt = (p.lk + KT - 1) / KT;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned smem_base =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int sr = lane >> 3, sp = lane & 7;
+  auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < IP; ++i) {
+      const int row = 8 * (wave_u * IP + i) + sr;
+      int key = kt * KT + row;
+      if (key >= p.lk) key = p.lk - 1;
+      const int64_t roff = (int64_t)key * p.k_sl;
+      const unsigned dst = smem_base + buf * BUF_BYTES + 8 * (wave_u * IP + i) * 128;
+      glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
+      glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
+    }
+  };
+  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+  typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+  auto tile = [&](auto buf_c, auto masked_c, int kt) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool MASKED = decltype(masked_c)::value;
+    const char* const lds_k = smem + BUF * BUF_BYTES;
+    const char* const lds_v = lds_k + KT * 128;
+    const bool more2 = kt + 2 < nt;
+    if (more2) issue_tile(kt + 2, (BUF + 2) % 3);
+
+    f32x16 sc[QB][KB];
+    half8_t pf[QB][KB][2];
+    // S^T = K Q^T, accumulators start at -m_run (q carries scale*log2e)
+    auto qk = [&](int c) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int krow = 32 * kb + qi;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const half8_t kf = *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
+          if (s == 0) {
+            f32x16 c0;
+            const float init = -m_run[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c0[r] = init;
+            sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c][s], c0, 0, 0, 0);
+          } else {
+            sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c][s], sc[c][kb], 0, 0, 0);
+          }
+        }
+      }
+    };
+    auto softmax = [&](int c) {
+      if (MASKED) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= p.lk) sc[c][kb][r] = -1e30f;
+          }
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[c][kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const bool first = kt == 0;
+      if (first || __any(mx > RESCALE_THR)) {  // wave-uniform
+        const float delta = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        m_run[c] += delta;
+        l_run[c] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc_o[c][d][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[c][kb][r] -= delta;
+      }
+      const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
+      float ls0 = 0.f, ls1 = 0.f;  // two partial sums: shorter dependent dot2 chains
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          fp16x2_t pk[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float e0 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j]);
+            const float e1 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j + 1]);
+            pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+            if (j & 1) ls1 = __builtin_amdgcn_fdot2(pk[j], ones2, ls1, false);
+            else ls0 = __builtin_amdgcn_fdot2(pk[j], ones2, ls0, false);
+          }
+          pf[c][kb][s2] = __builtin_bit_cast(half8_t, pk);
+        }
+      l_run[c] += ls0 + ls1;
+    };
+    auto pv = [&](int c) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int r0 = 32 * kb + 16 * s2 + 4 * hh;
+            const int colbyte = (32 * db + 16 * (g16 & 1) + 4 * p4) * 2;
+            const int ch = colbyte >> 4, within = colbyte & 15;
+            const int ra = r0 + q4, rb = r0 + 8 + q4;
+            const half8_t vf = tr_read_pair(lds_v + ra * 128 + (v_chunk_swz(ra, ch) << 4) + within,
+                                            lds_v + rb * 128 + (v_chunk_swz(rb, ch) << 4) + within);
+            acc_o[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c][kb][s2], acc_o[c][db], 0, 0, 0);
+          }
+    };
+    qk(0);
+    qk(1);
+    softmax(0);
+    pv(0);
+    softmax(1);
+    pv(1);
+    if (more2) wait_vm<G>();
+    else wait_vm<0>();
+    __syncthreads();
+  };
+
+  issue_tile(0, 0);
+  if (nt > 1) {
+    issue_tile(1, 1);
+    wait_vm<G>();
+  } else {
+    wait_vm<0>();
+  }
+#pragma unroll
+  for (int c = 0; c < QB; ++c)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[c][s]));  // retire the Q loads (see attn_kernel)
+  __syncthreads();
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using B2 = std::integral_constant<int, 2>;
+  const int nfull = p.lk / KT;
+  auto run = [&](auto buf_c, int kt) {
+    if (kt < nfull) tile(buf_c, std::false_type{}, kt);
+    else tile(buf_c, std::true_type{}, kt);
+  };
+  for (int kt = 0; kt < nt; kt += 3) {
+    run(B0{}, kt);
+    if (kt + 1 < nt) run(B1{}, kt + 1);
+    if (kt + 2 < nt) run(B2{}, kt + 2);
+  }
+
+  __syncthreads();  // every wave is done reading K/V tiles
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
+    const float inv = 1.0f / l_tot;
+    char* const ow = smem + (wave * QB + c) * (32 * 128);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        half4_t h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[c][db][4 * t + r] * inv);
+        const int d0 = 32 * db + 8 * t + 4 * hh;
+        const int chunk = d0 >> 3, piece = (d0 >> 2) & 1;
+        *(half4_t*)(ow + qi * 128 + ((chunk ^ (qi & 7)) << 4) + (piece << 3)) = h;
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    const char* const ow = smem + (wave * QB + c) * (32 * 128);
+    const int q0 = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (lane >> 3), pchunk = lane & 7;
+      const uint4 v = *(const uint4*)(ow + row * 128 + (pchunk << 4));
+      const int lchunk = pchunk ^ (row & 7);
+      if (q0 + row < p.lq) *(uint4*)(obase + (int64_t)(q0 + row) * p.o_sl + lchunk * 8) = v;
+    }
+  }
+}
+
 template <int NW, int KT>
 int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr, bool pre) {
   AttnArgs args = a;
@@ -416,5 +663,21 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   const bool pre = d->q_prescaled != 0;
   SEVA_REQUIRE(!pre || use_tr, "attention: q_prescaled is not available on the SEVA_ATTN_NO_TR debug path");
   if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr, pre);
+  // Two-chain kernel: opt-in (SEVA_ATTN_TWO=1).  Measured at the headline shapes it ties with attn_kernel
+  // (27.5 vs 27.3 ms/step): hipcc issues both chains' Q*K groups up front, the wave-uniform rescale
+  // branches split the tile into basic blocks it does not schedule across, and 38 + 32 register moves per
+  // tile appear at 251 VGPRs.  Kept, bit-compatible and tested, as the base for a hand-scheduled version.
+  const char* two = getenv("SEVA_ATTN_TWO");
+  if (pre && use_tr && !a.dbg && d->lq >= 512 && two && two[0] == '1') {
+    AttnArgs args = a;
+    args.qblocks = (a.lq + 255) / 256;
+    const int64_t nb = batch * a.heads * args.qblocks;
+    if (nb <= 0 || nb > 0x7fffffff) {
+      seva_set_error("attention: bad grid %lld", (long long)nb);
+      return SEVA_ERR_ARG;
+    }
+    hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
+    return seva_check_launch("attn2_kernel");
+  }
   return launch<4, 64>(a, batch, s, use_tr, pre);
 }

@@ -193,14 +193,16 @@ QK_C = 0.125 * 1.4426950408889634
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 200, 200), (1, 1, 1701, 1701), (2, 3, 70, 5), (4, 2, 21, 21),
-                                       (1, 2, 33, 64), (2, 1, 500, 777)])
+                                       (1, 2, 33, 64), (2, 1, 500, 777), (2, 2, 1024, 900), (1, 3, 777, 1300)])
 @pytest.mark.parametrize("spike", [False, True])
-def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike):
+@pytest.mark.parametrize("two", ["0", "1"])
+def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, monkeypatch):
     """q already multiplied by scale*log2(e) (what the engine's QKV projection emits): the kernel starts
     its score accumulators at -m_run and exponentiates the MFMA output directly.  `spike` plants, late in
     the key sequence, keys that beat the running maximum by far more than the deferred-rescale threshold
     (rescale branch), and shifts all logits of the first tile far below zero (first-tile reference)."""
     from seva import ops
+    monkeypatch.setenv("SEVA_ATTN_TWO", two)  # "1": the opt-in two-chain kernel for Lq >= 512
     C = 64 * H
     g = torch.Generator().manual_seed(31)
     q = torch.randn((B, Lq, H, 64), generator=g)
