@@ -207,6 +207,22 @@ int seva_scale_rows_f32(const float* x, const float* s, float* out, int32_t n, i
                         seva_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Conditioning geometry.
+ * Pluecker ray maps, seva/geometry.py:119-165 (get_plucker_coordinates) with get_center_and_ray
+ * (102-116) and get_image_grid (82-89): out[v][0:3][y][x] = unit ray direction of latent pixel
+ * (x+0.5, y+0.5) of view v, out[v][3:6] = camera centre x direction, all in the source camera's frame.
+ * kinv [views][9]: row-major inverse of view v's intrinsics in latent-pixel units;
+ * pose_inv [views][12]: rows of inverse(to_hom(extrinsics_rel[v]))[:3, :4] (the two small matrix inverses
+ * per view stay on the host, as in the reference).  out: [views][6][h][w] fp32.
+ */
+int seva_plucker_f32(const float* kinv, const float* pose_inv, float* out, int32_t views, int32_t h,
+                     int32_t w, seva_stream_t stream);
+/* Channel assembly of do_sample (seva/eval.py:1255-1270): c_concat[v] = [mask[v] broadcast | plucker[v]],
+ * uc_concat[v] = [0 | plucker[v]]; both [views][7][h][w] fp32; mask: one byte per view. */
+int seva_cond_concat_f32(const float* plucker, const uint8_t* mask, float* c_concat, float* uc_concat,
+                         int32_t views, int32_t h, int32_t w, seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * hipGraph helpers: capture everything enqueued on `stream` between begin/end, replay later.
  */
 int seva_graph_begin(seva_stream_t stream);

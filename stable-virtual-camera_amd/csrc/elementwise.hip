@@ -213,6 +213,53 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
     out[i] = x[i] * s[i / chw];
 }
 
+// ---- conditioning geometry -------------------------------------------------------------------
+// Pluecker ray map of one latent pixel per thread, the arithmetic of seva/geometry.py:82-117,160-165 in its
+// order: grid (x+.5, y+.5, 1) -> camera (K^-1) -> source-camera frame (pose^-1, homogeneous) ; ray = point -
+// centre (kept as a subtraction, like the reference, so the rounding matches) ; normalise ; moment = centre x ray.
+__global__ void plucker_kernel(const float* __restrict__ kinv, const float* __restrict__ pose_inv,
+                               float* __restrict__ out, int h, int w) {
+  const int v = blockIdx.y;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= h * w) return;
+  const float* ki = kinv + v * 9;
+  const float* pi = pose_inv + v * 12;
+  const int y = pix / w, x = pix - y * w;
+  const float gx = (float)x + 0.5f, gy = (float)y + 0.5f;
+  float cam[3], wpt[3], ctr[3], ray[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cam[i] = gx * ki[3 * i] + gy * ki[3 * i + 1] + ki[3 * i + 2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    wpt[i] = cam[0] * pi[4 * i] + cam[1] * pi[4 * i + 1] + cam[2] * pi[4 * i + 2] + pi[4 * i + 3];
+    ctr[i] = pi[4 * i + 3];
+    ray[i] = wpt[i] - ctr[i];
+  }
+  const float nrm = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+  const float inv = 1.0f / fmaxf(nrm, 1e-12f);  // F.normalize eps
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ray[i] *= inv;
+  const float m0 = ctr[1] * ray[2] - ctr[2] * ray[1];
+  const float m1 = ctr[2] * ray[0] - ctr[0] * ray[2];
+  const float m2 = ctr[0] * ray[1] - ctr[1] * ray[0];
+  float* o = out + (int64_t)v * 6 * h * w + pix;
+  const int64_t cs = (int64_t)h * w;
+  o[0] = ray[0]; o[cs] = ray[1]; o[2 * cs] = ray[2];
+  o[3 * cs] = m0; o[4 * cs] = m1; o[5 * cs] = m2;
+}
+
+// concat channels of do_sample (seva/eval.py:1255-1270): c = [mask_v | plucker_v], uc = [0 | plucker_v]
+__global__ void cond_concat_kernel(const float* __restrict__ plucker, const unsigned char* __restrict__ mask,
+                                   float* __restrict__ c_concat, float* __restrict__ uc_concat, int hw) {
+  const int v = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 7*hw
+  if (i >= 7 * hw) return;
+  const int ch = i / hw;
+  const float val = ch == 0 ? 0.f : plucker[(int64_t)v * 6 * hw + (i - hw)];
+  c_concat[(int64_t)v * 7 * hw + i] = ch == 0 ? (mask[v] ? 1.f : 0.f) : val;
+  uc_concat[(int64_t)v * 7 * hw + i] = val;
+}
+
 }  // namespace
 
 #define EW_LAUNCH(kern, work, ...)                                                         \
@@ -337,4 +384,25 @@ extern "C" int seva_to_d_f32(const float* x, const float* den, const float* sigm
   SEVA_REQUIRE(x && den && sigma && out && n > 0 && chw > 0, "to_d: bad args");
   SevaProfScope prof(4, (double)n * chw * 12.0, (hipStream_t)stream);
   EW_LAUNCH(to_d_kernel, (int64_t)n * chw, x, den, sigma, out, n, chw);
+}
+
+extern "C" int seva_plucker_f32(const float* kinv, const float* pose_inv, float* out, int32_t views,
+                                int32_t h, int32_t w, seva_stream_t stream) {
+  SEVA_REQUIRE(kinv && pose_inv && out && views > 0 && h > 0 && w > 0, "plucker: bad args");
+  SEVA_REQUIRE(views <= 65535, "plucker: too many views");
+  hipStream_t s_ = (hipStream_t)stream;
+  SevaProfScope prof(4, (double)views * h * w * 24.0, s_);
+  hipLaunchKernelGGL(plucker_kernel, dim3((h * w + 255) / 256, views), dim3(256), 0, s_, kinv, pose_inv, out, h, w);
+  return seva_check_launch("plucker_kernel");
+}
+
+extern "C" int seva_cond_concat_f32(const float* plucker, const uint8_t* mask, float* c_concat, float* uc_concat,
+                                    int32_t views, int32_t h, int32_t w, seva_stream_t stream) {
+  SEVA_REQUIRE(plucker && mask && c_concat && uc_concat && views > 0 && h > 0 && w > 0, "cond_concat: bad args");
+  SEVA_REQUIRE(views <= 65535, "cond_concat: too many views");
+  hipStream_t s_ = (hipStream_t)stream;
+  SevaProfScope prof(4, (double)views * h * w * 80.0, s_);
+  hipLaunchKernelGGL(cond_concat_kernel, dim3((7 * h * w + 255) / 256, views), dim3(256), 0, s_, plucker, mask,
+                     c_concat, uc_concat, h * w);
+  return seva_check_launch("cond_concat_kernel");
 }

@@ -85,6 +85,8 @@ SYMBOLS = {
     "seva_euler_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "seva_to_d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "seva_scale_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+    "seva_plucker_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "seva_cond_concat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "seva_graph_begin": (c_int, [c_void_p]),
     "seva_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "seva_graph_launch": (c_int, [c_void_p, c_void_p]),

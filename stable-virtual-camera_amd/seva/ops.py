@@ -301,6 +301,30 @@ def scale_rows(x: torch.Tensor, s: torch.Tensor, out: torch.Tensor) -> None:
                                      x.numel() // n, stream_ptr(x.device)), "seva_scale_rows_f32")
 
 
+def plucker(kinv: torch.Tensor, pose_inv: torch.Tensor, out: torch.Tensor) -> None:
+    """out[v] (6,h,w) = Pluecker map of view v from its inverse intrinsics (3x3, latent-pixel units) and the
+    inverse relative pose rows (3x4) (seva_plucker_f32)."""
+    require_cuda(kinv, pose_inv, out)
+    assert kinv.dtype == F32 and pose_inv.dtype == F32 and out.dtype == F32
+    assert kinv.is_contiguous() and pose_inv.is_contiguous() and out.is_contiguous()
+    V, six, h, w = out.shape
+    assert six == 6 and kinv.shape == (V, 3, 3) and pose_inv.shape == (V, 3, 4)
+    check(_lib().seva_plucker_f32(kinv.data_ptr(), pose_inv.data_ptr(), out.data_ptr(), V, h, w,
+                                  stream_ptr(out.device)), "seva_plucker_f32")
+
+
+def cond_concat(plucker_maps: torch.Tensor, mask_u8: torch.Tensor, c_concat: torch.Tensor, uc_concat: torch.Tensor) -> None:
+    """c_concat = [mask | plucker], uc_concat = [0 | plucker] (seva_cond_concat_f32)."""
+    require_cuda(plucker_maps, mask_u8, c_concat, uc_concat)
+    V, six, h, w = plucker_maps.shape
+    assert six == 6 and mask_u8.dtype == torch.uint8 and mask_u8.numel() == V
+    assert c_concat.shape == (V, 7, h, w) and uc_concat.shape == (V, 7, h, w)
+    assert plucker_maps.is_contiguous() and c_concat.is_contiguous() and uc_concat.is_contiguous()
+    check(_lib().seva_cond_concat_f32(plucker_maps.data_ptr(), mask_u8.data_ptr(), c_concat.data_ptr(),
+                                      uc_concat.data_ptr(), V, h, w, stream_ptr(plucker_maps.device)),
+          "seva_cond_concat_f32")
+
+
 # --- profiling / graphs ---------------------------------------------------------------------
 def prof_enable(on: bool) -> None:
     check(_lib().seva_prof_enable(1 if on else 0))

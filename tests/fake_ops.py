@@ -179,3 +179,24 @@ def to_d(x, den, sigma, out):
 
 def scale_rows(x, s, out):
     out.copy_(x * _rows(s, x))
+
+
+def plucker(kinv, pose_inv, out):
+    V, _, h, w = out.shape
+    ys = torch.arange(h, dtype=torch.float32) + 0.5
+    xs = torch.arange(w, dtype=torch.float32) + 0.5
+    Y, X = torch.meshgrid(ys, xs, indexing="ij")
+    grid = torch.stack([X, Y, torch.ones_like(X)], -1).view(-1, 3)
+    cam = grid[None] @ kinv.transpose(-1, -2)
+    world = cam @ pose_inv[:, :, :3].transpose(-1, -2) + pose_inv[:, None, :, 3]
+    ctr = pose_inv[:, None, :, 3].expand_as(world)
+    ray = F.normalize(world - ctr, dim=-1)
+    out.copy_(torch.cat([ray, torch.linalg.cross(ctr, ray, dim=-1)], -1).permute(0, 2, 1).reshape(V, 6, h, w))
+
+
+def cond_concat(plucker_maps, mask_u8, c_concat, uc_concat):
+    V, _, h, w = plucker_maps.shape
+    c_concat[:, 1:] = plucker_maps
+    uc_concat[:, 1:] = plucker_maps
+    c_concat[:, 0] = mask_u8.float()[:, None, None]
+    uc_concat[:, 0] = 0

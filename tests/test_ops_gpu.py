@@ -465,3 +465,49 @@ def test_attention_running_max_paths(dev, slope):
     ref = _attn_ref(r(qh), r(kh), r(vh), 0.125).transpose(1, 2).reshape(B, L, C)
     err = rel_l2(out, ref)
     assert torch.isfinite(out.float()).all() and err < 2e-3, f"slope {slope}: rel_l2 {err}"
+
+
+# ---- conditioning geometry ----------------------------------------------------------------------
+def test_plucker_matches_reference_golden(dev):
+    """seva.geometry.get_plucker_coordinates (HIP) against vectors produced by the reference itself."""
+    from conftest import load_golden
+    from seva import geometry as G
+    g = load_golden("g8_plucker")
+    t = lambda k: torch.as_tensor(g[k]).clone()
+    a = G.get_plucker_coordinates(t("a_w2c")[0].to(dev), t("a_w2c").to(dev), None, target_size=[9, 9])
+    assert a.device.type == "cuda" and torch.allclose(a.cpu(), t("a_out"), atol=3e-6, rtol=0)
+    # host inputs: computed on the GPU, returned on the host; the intrinsics argument is rescaled in place like the reference's
+    Kb = t("b_K")
+    b = G.get_plucker_coordinates(t("b_w2c")[1], t("b_w2c"), Kb, target_size=[12, 20])
+    assert b.device.type == "cpu" and torch.allclose(b, t("b_out"), atol=3e-6, rtol=0)
+    assert torch.allclose(Kb[:, 0], t("b_K")[:, 0] * 20) and torch.allclose(Kb[:, 1], t("b_K")[:, 1] * 12)
+    c = G.get_plucker_coordinates(t("c_w2c")[0].to(dev), t("c_w2c").to(dev), t("c_K").to(dev), target_size=[8, 6])
+    assert torch.allclose(c.cpu(), t("c_out"), atol=3e-6, rtol=0)
+    bad = t("c_K") * 50.0
+    with pytest.raises(AssertionError):
+        G.get_plucker_coordinates(t("c_w2c")[0], t("c_w2c"), bad, target_size=[8, 6])
+
+
+def test_value_dict_and_cond_assembly(dev):
+    from conftest import load_golden
+    from oracle import geometry_ref as R
+    from seva import conditioning as Cn
+    g = load_golden("g8_value_dict")
+    for tag in ("a", "b", "c"):
+        H, W = (int(v) for v in g[f"{tag}_HW"])
+        c2w_in = torch.as_tensor(g[f"{tag}_c2w_in"]).clone()
+        vd = Cn.get_value_dict((H, W), [int(i) for i in g[f"{tag}_in_idx"]], c2w_in, torch.as_tensor(g[f"{tag}_K"]).clone(),
+                               R.to_hom_pose(c2w_in), 2.0, device=dev)
+        assert torch.equal(vd["cond_frames_mask"], torch.as_tensor(g[f"{tag}_mask"]))
+        assert torch.allclose(vd["c2w"], torch.as_tensor(g[f"{tag}_c2w"]), atol=1e-6, rtol=0)
+        assert torch.allclose(vd["plucker_coordinate"].cpu(), torch.as_tensor(g[f"{tag}_plucker"]), atol=4e-6, rtol=0)
+    # channel assembly against the oracle's restatement of do_sample
+    T, h, w = 5, 8, 8
+    pl = vd_pl = torch.randn(T, 6, h, w)
+    mask = torch.tensor([True, False, False, True, False])
+    lat, clip = torch.randn(2, 4, h, w), torch.randn(1024)
+    c_ref, uc_ref = R.assemble_cond(lat, clip, mask, pl)
+    c, uc = Cn.assemble_cond(lat, clip, mask, pl.to(dev))
+    for k in c_ref:
+        assert torch.equal(c[k].cpu(), c_ref[k]), k
+        assert torch.equal(uc[k].cpu(), uc_ref[k]), k

@@ -185,3 +185,30 @@ def test_g4_full_forward():
     c = {"crossattn": g["crossattn"], "concat": g["concat"], "dense_vector": g["dense_vector"]}
     y = O.sgm_wrapper_forward(sd, g["x"], g["t"], c, int(g["T"]))
     assert rel_l2(y, g["y"]) < 5e-5
+
+
+# ---- conditioning geometry -----------------------------------------------------------------------
+def test_geometry_plucker_matches_reference_golden():
+    from oracle import geometry_ref as G
+    g = load_golden("g8_plucker")
+    a = G.get_plucker_coordinates(torch.tensor(g["a_w2c"][0]), torch.tensor(g["a_w2c"]), None, target_size=(9, 9))
+    assert torch.allclose(a, torch.tensor(g["a_out"]), atol=2e-6, rtol=0)
+    b = G.get_plucker_coordinates(torch.tensor(g["b_w2c"][1]), torch.tensor(g["b_w2c"]), torch.tensor(g["b_K"]), target_size=(12, 20))
+    assert torch.allclose(b, torch.tensor(g["b_out"]), atol=2e-6, rtol=0)
+    c = G.get_plucker_coordinates(torch.tensor(g["c_w2c"][0]), torch.tensor(g["c_w2c"]), torch.tensor(g["c_K"]), target_size=(8, 6))
+    assert torch.allclose(c, torch.tensor(g["c_out"]), atol=2e-6, rtol=0)
+
+
+def test_geometry_value_dict_matches_reference_golden():
+    from oracle import geometry_ref as G
+    g = load_golden("g8_value_dict")
+    for tag in ("a", "b", "c"):
+        H, W = (int(v) for v in g[f"{tag}_HW"])
+        c2w_in = torch.tensor(g[f"{tag}_c2w_in"])
+        T = c2w_in.shape[0]
+        imgs = torch.zeros(T, 3, H, W)
+        vd = G.get_value_dict(imgs, [int(i) for i in g[f"{tag}_in_idx"]], c2w_in, torch.tensor(g[f"{tag}_K"]),
+                              G.to_hom_pose(c2w_in), 2.0)
+        assert torch.equal(vd["cond_frames_mask"], torch.tensor(g[f"{tag}_mask"]))
+        assert torch.allclose(vd["c2w"], torch.tensor(g[f"{tag}_c2w"]), atol=1e-6, rtol=0), tag
+        assert torch.allclose(vd["plucker_coordinate"], torch.tensor(g[f"{tag}_plucker"]), atol=3e-6, rtol=0), tag
