@@ -65,6 +65,7 @@ def make_sampler(net, device, T, hw, steps, seed):
     # step-invariant inputs assembled on the GPU: camera normalisation on the host, Pluecker maps
     # and the cond / uc channel assembly by HIP kernels; replaces the CPU-built dictionaries of synth_scene
     from seva import conditioning as Cn
+    Cn.get_value_dict((hw * 8, hw * 8), [0], sc["c2w"][:, :3], sc["K"], sc["c2w"], 2.0, device=device)  # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     vd = Cn.get_value_dict((hw * 8, hw * 8), [0], sc["c2w"][:, :3], sc["K"], sc["c2w"], 2.0, device=device)
