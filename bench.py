@@ -226,8 +226,16 @@ def main():
             img = ae.decode(zl)
             torch.cuda.synchronize()
         dtv = (time.perf_counter() - t1) / zl.shape[0]
+        with torch.no_grad():  # encode of the input / anchor views (reference autoencoder.py:21-35), chunk_size=1
+            ae.encode(img[:1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ae.encode(img)
+            torch.cuda.synchronize()
+        dte = (time.perf_counter() - t1) / img.shape[0]
         vae = {"ms_per_frame": dtv * 1e3, "frames_per_sec": 1.0 / dtv, "frame": f"{img.shape[-2]}x{img.shape[-1]}",
-               "weights": "random-init SD-2.1 VAE decoder topology (parity unpinned)"}
+               "encode_ms_per_frame": dte * 1e3,
+               "weights": "random-init SD-2.1 VAE topology (parity unpinned)"}
         del ae
 
     if rank == 0:

@@ -75,6 +75,9 @@ typedef struct seva_gemm_desc {
    * softmax scale * log2(e) into the q third of a fused QKV projection. */
   float col_scale;
   int32_t col_scale_n;
+  /* conv mode: 1 = zero padding only at the bottom / right edge (taps start AT pixel (stride*oy, stride*ox)); the
+   * stride-2 Downsample2D of the diffusers VAE encoder pads (0,1,0,1).  0 = symmetric pad 1 (every UNet conv). */
+  int32_t pad_br_only;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 

@@ -1,4 +1,4 @@
-"""CPU oracle for the SD-2.1 VAE *decoder* -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+"""CPU oracle for the SD-2.1 VAE (decoder and encoder) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 **Parity unpinned.**  The reference delegates decoding to the third-party `diffusers` package
 (`/root/reference/seva/modules/autoencoder.py:2,12-17,38`; `pyproject.toml:22`, version unpinned),
@@ -108,3 +108,70 @@ def vae_decode(sd: dict, z: torch.Tensor) -> torch.Tensor:
         i += 1
     x = F.silu(_gn(sd, "decoder.conv_norm_out", x))
     return _conv(sd, "decoder.conv_out", x, 1)
+
+
+# ---- encoder (reference autoencoder.py:21-35 -> AutoencoderKL.encode(x).latent_dist.mean * 0.18215) ----
+def encoder_shapes(block_out=BLOCK_OUT, latent=4, in_ch=3) -> dict[str, tuple]:
+    """state_dict keys/shapes of the encoder half (+quant_conv) in diffusers naming (published SD-2.1 VAE config:
+    down blocks of LAYERS_PER_BLOCK resnets, a stride-2 conv after all but the last, mid block with one attention,
+    GN+SiLU+conv to 2*latent moments)."""
+    s: dict[str, tuple] = {}
+
+    def conv(p, cin, cout, k):
+        s[p + ".weight"], s[p + ".bias"] = (cout, cin, k, k), (cout,)
+
+    def norm(p, c):
+        s[p + ".weight"], s[p + ".bias"] = (c,), (c,)
+
+    def lin(p, cin, cout):
+        s[p + ".weight"], s[p + ".bias"] = (cout, cin), (cout,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin); conv(p + ".conv1", cin, cout, 3)
+        norm(p + ".norm2", cout); conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".conv_shortcut", cin, cout, 1)
+
+    conv("encoder.conv_in", in_ch, block_out[0], 3)
+    cin = block_out[0]
+    for i, cout in enumerate(block_out):
+        for j in range(LAYERS_PER_BLOCK):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        cin = cout
+        if i != len(block_out) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+    top = block_out[-1]
+    resnet("encoder.mid_block.resnets.0", top, top)
+    a = "encoder.mid_block.attentions.0"
+    norm(a + ".group_norm", top)
+    for n in ("to_q", "to_k", "to_v"):
+        lin(f"{a}.{n}", top, top)
+    lin(a + ".to_out.0", top, top)
+    resnet("encoder.mid_block.resnets.1", top, top)
+    norm("encoder.conv_norm_out", top)
+    conv("encoder.conv_out", top, 2 * latent, 3)
+    conv("quant_conv", 2 * latent, 2 * latent, 1)
+    return s
+
+
+def vae_encode(sd: dict, x: torch.Tensor) -> torch.Tensor:
+    """AutoEncoder._encode (reference autoencoder.py:21-25): mean of the diagonal Gaussian, times 0.18215.
+    Downsample2D pads (0,1,0,1) and convolves with stride 2, padding 0."""
+    latent = sd["quant_conv.weight"].shape[0] // 2
+    h = _conv(sd, "encoder.conv_in", x, 1)
+    i = 0
+    while f"encoder.down_blocks.{i}.resnets.0.norm1.weight" in sd:
+        j = 0
+        while f"encoder.down_blocks.{i}.resnets.{j}.norm1.weight" in sd:
+            h = _resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", h)
+            j += 1
+        dn = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+        if dn + ".weight" in sd:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[dn + ".weight"], sd[dn + ".bias"], stride=2)
+        i += 1
+    h = _resnet(sd, "encoder.mid_block.resnets.0", h)
+    h = _attn(sd, "encoder.mid_block.attentions.0", h)
+    h = _resnet(sd, "encoder.mid_block.resnets.1", h)
+    h = _conv(sd, "encoder.conv_out", F.silu(_gn(sd, "encoder.conv_norm_out", h)), 1)
+    moments = _conv(sd, "quant_conv", h, 0)
+    return moments[:, :latent] * SCALE_FACTOR

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       const int img = (int)(m / ohw);
       const int rem = (int)(m - (int64_t)img * ohw);
       const int oy = rem / p.ow, ox = rem - oy * p.ow;
-      a_by[i] = oy * p.stride - 1;
-      a_bx[i] = ox * p.stride - 1;
+      a_by[i] = oy * p.stride - p.pad_lo;
+      a_bx[i] = ox * p.stride - p.pad_lo;
       a_img[i] = (int64_t)img * p.ih * p.iw * p.cin;
       a_ptr[i] = nullptr;
     }
@@ -680,12 +680,14 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
     SEVA_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
     SEVA_REQUIRE(!(d->upsample && d->stride != 1), "conv: upsample needs stride 1");
     const int eh = d->upsample ? 2 * d->ih : d->ih, ew = d->upsample ? 2 * d->iw : d->iw;
-    SEVA_REQUIRE(d->oh == (eh + 2 - 3) / d->stride + 1 && d->ow == (ew + 2 - 3) / d->stride + 1,
-                 "conv: output %dx%d inconsistent with input %dx%d stride %d up %d", d->oh, d->ow,
-                 d->ih, d->iw, d->stride, d->upsample);
+    const int pad_sum = d->pad_br_only ? 1 : 2;
+    SEVA_REQUIRE(d->oh == (eh + pad_sum - 3) / d->stride + 1 && d->ow == (ew + pad_sum - 3) / d->stride + 1,
+                 "conv: output %dx%d inconsistent with input %dx%d stride %d up %d pad_br_only %d", d->oh, d->ow,
+                 d->ih, d->iw, d->stride, d->upsample, d->pad_br_only);
     SEVA_REQUIRE(d->M == (int64_t)d->n * d->oh * d->ow, "conv: M != n*oh*ow");
     a.n = d->n; a.ih = d->ih; a.iw = d->iw; a.cin = d->cin; a.oh = d->oh; a.ow = d->ow;
     a.stride = d->stride; a.upsample = d->upsample;
+    a.pad_lo = d->pad_br_only ? 0 : 1;
   } else {
     SEVA_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda=%lld invalid", (long long)d->lda);
   }

@@ -16,6 +16,7 @@ struct SevaGemmArgs {
   int64_t lda, ldr, ldo32, ldo16;
   int64_t rows_per_group, ldra;
   int32_t n, ih, iw, cin, oh, ow, stride, upsample;
+  int32_t pad_lo;    // conv: zero rows/cols before pixel 0 (1, or 0 for bottom/right-only padding)
   int32_t tiles_m, tiles_n;
   int32_t n_chunks;  // each block walks tiles_n / n_chunks consecutive N-tiles of one M-tile
   float col_scale;   // features < col_scale_n are multiplied by col_scale (plain epilogue)

@@ -413,8 +413,8 @@ int launch_phase(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int seva_gemm_phase_launch(const GemmArgs& a, int mode, int epilogue, hipStream_t s) {
-  if (a.col_scale_n > 0) {
-    seva_set_error("experimental gemm kernels do not implement col_scale");
+  if (a.col_scale_n > 0 || (mode == 1 && a.pad_lo != 1)) {
+    seva_set_error("experimental gemm kernels do not implement col_scale / bottom-right-only padding");
     return SEVA_ERR_UNSUPPORTED;
   }
   if (epilogue == 1) return launch_phase<0, 1>(a, s);

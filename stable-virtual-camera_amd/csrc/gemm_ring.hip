@@ -303,8 +303,8 @@ int launch_ring(const GemmArgs& a, hipStream_t s, int blocks_per_cu = 1) {
 }  // namespace
 
 int seva_gemm_ring_launch(const GemmArgs& a, int mode, int epilogue, int cfg, hipStream_t s) {
-  if (a.col_scale_n > 0) {
-    seva_set_error("experimental gemm kernels do not implement col_scale");
+  if (a.col_scale_n > 0 || (mode == 1 && a.pad_lo != 1)) {
+    seva_set_error("experimental gemm kernels do not implement col_scale / bottom-right-only padding");
     return SEVA_ERR_UNSUPPORTED;
   }
   if (cfg == 3) {  // 128x128x32, 4 stages (64 KB LDS -> 2 workgroups per CU), waves 2x2: 64x64 per wave

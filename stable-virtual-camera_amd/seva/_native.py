@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
 
@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("mode", c_int32), ("epilogue", c_int32),
         ("n", c_int32), ("ih", c_int32), ("iw", c_int32), ("cin", c_int32),
         ("oh", c_int32), ("ow", c_int32), ("stride", c_int32), ("upsample", c_int32),
-        ("col_scale", c_float), ("col_scale_n", c_int32),
+        ("col_scale", c_float), ("col_scale_n", c_int32), ("pad_br_only", c_int32),
     ]
 
 

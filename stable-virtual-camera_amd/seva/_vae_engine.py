@@ -1,5 +1,5 @@
-"""HIP execution of the SD-2.1 VAE decoder (reference seva/modules/autoencoder.py:37-48 ->
-diffusers AutoencoderKL.decode).  Same kernels and layout rules as the UNet engine: channels-last
+"""HIP execution of the SD-2.1 VAE: decoder (reference seva/modules/autoencoder.py:37-48 -> diffusers
+AutoencoderKL.decode) and encoder (autoencoder.py:21-35 -> AutoencoderKL.encode(x).latent_dist.mean).  Same kernels and layout rules as the UNet engine: channels-last
 fp32 stream, fp16 GEMM operands, 3x3 convs as implicit GEMM with the nearest-2x upsample fused
 into the gather.  The single-head d=512 mid-block attention runs as GEMM(QK^T) -> row softmax ->
 GEMM(P V^T) with V produced already transposed by swapping the GEMM operand roles; the value
@@ -17,12 +17,15 @@ from ._native import SevaNativeError, require_cuda
 F16, F32 = torch.float16, torch.float32
 
 
-class VaeDecoderEngine:
+class _VaeEngineBase:
+    PREFIXES: tuple = ()       # state_dict key prefixes this half owns
+    CONV_IN = CONV_OUT = ""    # first conv (input channels padded to 64) / last conv (handled by the subclass)
+
     @staticmethod
     def _resolve_device(weights) -> torch.device:
         params = list(weights.parameters())
         if not params or params[0].device.type != "cuda":
-            raise SevaNativeError("AutoEncoder.decode runs only on an AMD GPU (no CPU fallback): call .to('cuda')")
+            raise SevaNativeError("AutoEncoder runs only on an AMD GPU (no CPU fallback): call .to('cuda')")
         from . import _native
 
         _native.load()
@@ -34,7 +37,7 @@ class VaeDecoderEngine:
         self.out_channels = weights.out_channels
         self.latent = weights.latent_channels
         self.arena = _Arena(self.device)
-        sd = {k: v.detach().to(self.device) for k, v in weights.state_dict().items()}
+        sd = {k: v.detach().to(self.device) for k, v in weights.state_dict().items() if k.startswith(self.PREFIXES)}
         W = {}
 
         def conv3(p, cin_pad=None, cout_pad=None):
@@ -61,19 +64,16 @@ class VaeDecoderEngine:
             if len(shp) == 1:
                 norm(p)
             elif len(shp) == 2 or shp[-1] == 1:
-                if p != "post_quant_conv":
+                if p not in ("post_quant_conv", "quant_conv"):
                     lin(p)
-            elif p == "decoder.conv_in":
+            elif p == self.CONV_IN:
                 conv3(p, cin_pad=CIN_PAD)
-            elif p == "decoder.conv_out":
-                conv3(p, cout_pad=4)
+            elif p == self.CONV_OUT:
+                pass  # subclass
             else:
                 conv3(p)
-        # post_quant_conv (1x1, 4->4) as a GEMM over the 64-channel padded latent image
-        wq = torch.zeros((self.latent, CIN_PAD), dtype=F16, device=self.device)
-        wq[:, : self.latent] = sd["post_quant_conv.weight"].reshape(self.latent, self.latent).to(F16)
-        W["post_quant_conv.w"], W["post_quant_conv.b"] = wq, sd["post_quant_conv.bias"].float().contiguous()
         self.W = W
+        self._pack_ends(sd, conv3)
 
     def _buf(self, name, shape, dtype, zero=False):
         key = (name, tuple(int(s) for s in shape), dtype)
@@ -130,6 +130,19 @@ class VaeDecoderEngine:
                  out_f32=out.view(n * hw, c))
         return out
 
+
+
+class VaeDecoderEngine(_VaeEngineBase):
+    PREFIXES = ("decoder.", "post_quant_conv.")
+    CONV_IN, CONV_OUT = "decoder.conv_in", "decoder.conv_out"
+
+    def _pack_ends(self, sd, conv3):
+        conv3("decoder.conv_out", cout_pad=4)
+        # post_quant_conv (1x1, 4->4) as a GEMM over the 64-channel padded latent image
+        wq = torch.zeros((self.latent, CIN_PAD), dtype=F16, device=self.device)
+        wq[:, : self.latent] = sd["post_quant_conv.weight"].reshape(self.latent, self.latent).to(F16)
+        self.W["post_quant_conv.w"], self.W["post_quant_conv.b"] = wq, sd["post_quant_conv.bias"].float().contiguous()
+
     @torch.no_grad()
     def decode(self, z: torch.Tensor, scale_factor: float) -> torch.Tensor:
         require_cuda(z)
@@ -171,4 +184,62 @@ class VaeDecoderEngine:
         ops.conv3x3(g16.view(n, h, w, c), W["decoder.conv_out.w"], bias=W["decoder.conv_out.b"], out_f32=o4)
         out = torch.empty((n, self.out_channels, h, w), dtype=F32, device=self.device)
         ops.nhwc_to_nchw_f32(o4, out)
+        return out
+
+
+class VaeEncoderEngine(_VaeEngineBase):
+    """x (n,3,H,W) in [-1,1] -> mean latent * scale_factor (n,4,H/8,W/8).  `quant_conv` (1x1) is folded into
+    `encoder.conv_out` at pack time in fp64 and only the mean half of the moments is produced."""
+
+    PREFIXES = ("encoder.", "quant_conv.")
+    CONV_IN, CONV_OUT = "encoder.conv_in", "encoder.conv_out"
+
+    def _pack_ends(self, sd, conv3):
+        L = self.latent
+        wo, bo = sd["encoder.conv_out.weight"].double(), sd["encoder.conv_out.bias"].double()
+        wq = sd["quant_conv.weight"].double().reshape(2 * L, 2 * L)[:L]  # mean rows only
+        w = (wq @ wo.reshape(2 * L, -1)).reshape(L, *wo.shape[1:])
+        b = wq @ bo + sd["quant_conv.bias"].double()[:L]
+        self.W["enc_out.w"], self.W["enc_out.b"] = pack_conv3x3(w.float()), b.float().contiguous()
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, scale_factor: float) -> torch.Tensor:
+        require_cuda(x)
+        W = self.W
+        x = x.to(F32).contiguous()
+        n, cx, h, w = x.shape
+        nd = len(self.block_out) - 1
+        if h % (1 << nd) or w % (1 << nd):
+            raise ValueError(f"VAE encode needs H and W divisible by {1 << nd} (got {h}x{w})")
+        self.gn_ws = self._buf("gn_ws", (n * 64 * 32 * 2,), F32)
+        one = torch.ones((n,), dtype=F32, device=self.device)
+        x16 = self._buf("v_x16", (n, h * w, CIN_PAD), F16)
+        ops.nchw_to_nhwc_f16(x, None, x16, scale=one)  # channels-last, 3 -> 64 zero-padded channels
+        c0 = self.block_out[0]
+        cur = self._buf("out:enc_in", (n, h * w, c0), F32)
+        ops.conv3x3(x16.view(n, h, w, CIN_PAD), W["encoder.conv_in.w"], bias=W["encoder.conv_in.b"], out_f32=cur)
+        cin = c0
+        for i, cout in enumerate(self.block_out):
+            for j in range(2):
+                cur = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", cur, n, h, w, cin if j == 0 else cout, cout)
+            cin = cout
+            if i != nd:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                d16 = self._buf("v_dn16", (n, h, w, cout), F16)
+                ops.cast_concat_f16(cur, None, d16)
+                h, w = h // 2, w // 2
+                cur = self._buf("out:" + p, (n, h * w, cout), F32)
+                ops.conv3x3(d16, W[p + ".w"], stride=2, pad_br_only=True, bias=W[p + ".b"], out_f32=cur)
+        top = self.block_out[-1]
+        cur = self._resnet("encoder.mid_block.resnets.0", cur, n, h, w, top, top)
+        cur = self._attention("encoder.mid_block.attentions.0", cur, n, h, w, top)
+        cur = self._resnet("encoder.mid_block.resnets.1", cur, n, h, w, top, top)
+        g16 = self._buf("gn16", (n, h * w, top), F16)
+        ops.groupnorm(cur, None, W["encoder.conv_norm_out.g"], W["encoder.conv_norm_out.b"], g16, self.gn_ws,
+                      eps=1e-6, silu=True)
+        o4 = self._buf("v_m4", (n, h * w, self.latent), F32)
+        ops.conv3x3(g16.view(n, h, w, top), W["enc_out.w"], bias=W["enc_out.b"], out_f32=o4)
+        out = torch.empty((n, self.latent, h, w), dtype=F32, device=self.device)
+        ops.nhwc_to_nchw_f32(o4, out)
+        ops.scale_rows(out, torch.full((n,), float(scale_factor), dtype=F32, device=self.device), out)
         return out

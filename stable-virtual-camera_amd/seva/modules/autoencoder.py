@@ -2,13 +2,14 @@
 
 The reference delegates to `diffusers.AutoencoderKL.from_pretrained("stabilityai/stable-diffusion-2-1-base",
 subfolder="vae")` (autoencoder.py:12-17).  Neither diffusers nor the weights are available offline, so this
-module owns (a) a parameter holder with diffusers' decoder key names (`post_quant_conv.*`, `decoder.*`), so a
-real `diffusion_pytorch_model.safetensors` loads with `load_state_dict(strict=False)`, and (b) the decode path
-on the HIP kernels (`seva/_vae_engine.py`).  Parity with diffusers is UNPINNED (no fixture can be made here);
+module owns (a) a parameter holder with diffusers' key names (`encoder.*`, `quant_conv.*`, `post_quant_conv.*`,
+`decoder.*`), so a real `diffusion_pytorch_model.safetensors` loads with `load_state_dict(strict=False)`, and (b) the
+encode and decode paths on the HIP kernels (`seva/_vae_engine.py`).  Parity with diffusers is UNPINNED (no fixture can be made here);
 tests compare against our own restatement of the published topology.
 
 Kept API: `AutoEncoder(chunk_size=None)`, `.encode(x, chunk_size)`, `.decode(z, chunk_size)`, `.to(device)`,
-`scale_factor`, `downsample`.  `encode` is a next-row item and raises.
+`scale_factor`, `downsample`.  `encode` returns the mean of the latent distribution times 0.18215,
+as the reference does (autoencoder.py:21-25).
 """
 
 from __future__ import annotations
@@ -73,13 +74,49 @@ class VaeDecoderWeights(_Holder):
         self.put("decoder.conv_out", nn.Conv2d(rev[-1], out_channels, 3, padding=1))
 
 
+class VaeWeights(VaeDecoderWeights):
+    """Encoder + decoder of the SD-2.1 AutoencoderKL (published config), diffusers key names."""
+
+    def __init__(self, block_out=BLOCK_OUT, latent_channels: int = 4, out_channels: int = 3, in_channels: int = 3):
+        super().__init__(block_out, latent_channels, out_channels)
+        self.in_channels = in_channels
+
+        def resnet(p, cin, cout):
+            self.put(p + ".norm1", nn.GroupNorm(32, cin, eps=1e-6))
+            self.put(p + ".conv1", nn.Conv2d(cin, cout, 3, padding=1))
+            self.put(p + ".norm2", nn.GroupNorm(32, cout, eps=1e-6))
+            self.put(p + ".conv2", nn.Conv2d(cout, cout, 3, padding=1))
+            if cin != cout:
+                self.put(p + ".conv_shortcut", nn.Conv2d(cin, cout, 1))
+
+        self.put("encoder.conv_in", nn.Conv2d(in_channels, block_out[0], 3, padding=1))
+        cin = block_out[0]
+        for i, cout in enumerate(block_out):
+            for j in range(LAYERS_PER_BLOCK):
+                resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+            cin = cout
+            if i != len(block_out) - 1:
+                self.put(f"encoder.down_blocks.{i}.downsamplers.0.conv", nn.Conv2d(cout, cout, 3, stride=2, padding=0))
+        top = block_out[-1]
+        resnet("encoder.mid_block.resnets.0", top, top)
+        a = "encoder.mid_block.attentions.0"
+        self.put(a + ".group_norm", nn.GroupNorm(32, top, eps=1e-6))
+        for n in ("to_q", "to_k", "to_v"):
+            self.put(f"{a}.{n}", nn.Linear(top, top))
+        self.put(a + ".to_out.0", nn.Linear(top, top))
+        resnet("encoder.mid_block.resnets.1", top, top)
+        self.put("encoder.conv_norm_out", nn.GroupNorm(32, top, eps=1e-6))
+        self.put("encoder.conv_out", nn.Conv2d(top, 2 * latent_channels, 3, padding=1))
+        self.put("quant_conv", nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1))
+
+
 class AutoEncoder(nn.Module):
     scale_factor: float = 0.18215
     downsample: int = 8
 
     def __init__(self, chunk_size: int | None = None):
         super().__init__()
-        self.module = VaeDecoderWeights()
+        self.module = VaeWeights()
         path = os.environ.get("SEVA_VAE_PATH")  # local diffusers VAE safetensors, if the user has one
         if path:
             import safetensors.torch
@@ -88,14 +125,22 @@ class AutoEncoder(nn.Module):
         self.module.eval().requires_grad_(False)
         self.chunk_size = chunk_size
         self._engine = None
+        self._enc_engine = None
 
     def _apply(self, fn, *a, **k):
-        self._engine = None
+        self._engine = self._enc_engine = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._engine = None
+        self._engine = self._enc_engine = None
         return super().load_state_dict(*a, **k)
+
+    def encoder_engine(self):
+        if self._enc_engine is None:
+            from .._vae_engine import VaeEncoderEngine
+
+            self._enc_engine = VaeEncoderEngine(self.module)
+        return self._enc_engine
 
     def engine(self):
         if self._engine is None:
@@ -105,11 +150,12 @@ class AutoEncoder(nn.Module):
         return self._engine
 
     def _encode(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(
-            "VAE encode is not part of this round's hot path (SURVEY.md §8f N1); decode only."
-        )
+        return self.encoder_engine().encode(x, self.scale_factor)
 
     def encode(self, x: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
+        chunk_size = chunk_size or self.chunk_size
+        if chunk_size is not None:
+            return torch.cat([self._encode(xc) for xc in x.split(chunk_size)], dim=0)
         return self._encode(x)
 
     def _decode(self, z: torch.Tensor) -> torch.Tensor:

@@ -71,13 +71,16 @@ def conv3x3(
     residual: torch.Tensor | None = None,
     out_f32: torch.Tensor | None = None,
     out_f16: torch.Tensor | None = None,
+    pad_br_only: bool = False,
 ) -> None:
-    """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16."""
+    """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16.
+    pad_br_only: zero padding at the bottom / right edge only (diffusers Downsample2D, pad (0,1,0,1))."""
     require_cuda(x, w)
     assert x.dtype == F16 and w.dtype == F16 and x.dim() == 4 and x.is_contiguous()
     n, ih, iw, cin = x.shape
     eh, ew = (2 * ih, 2 * iw) if upsample else (ih, iw)
-    oh, ow = (eh - 1) // stride + 1, (ew - 1) // stride + 1
+    ps = 1 if pad_br_only else 2
+    oh, ow = (eh + ps - 3) // stride + 1, (ew + ps - 3) // stride + 1
     d = GemmDesc()
     d.a, d.w = x.data_ptr(), w.data_ptr()
     d.bias, d.row_add, d.residual = ptr(bias), ptr(row_add), ptr(residual)
@@ -91,6 +94,7 @@ def conv3x3(
     d.mode, d.epilogue = 1, 0
     d.n, d.ih, d.iw, d.cin, d.oh, d.ow = n, ih, iw, cin, oh, ow
     d.stride, d.upsample = stride, 1 if upsample else 0
+    d.pad_br_only = 1 if pad_br_only else 0
     check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(x.device)), "seva_gemm_f16(conv)")
 
 

@@ -47,14 +47,17 @@ def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, resid
 
 
 def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
-            ld_row_add=0, residual=None, out_f32=None, out_f16=None):
+            ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False):
     n, ih, iw, cin = x.shape
     assert x.dtype == F16 and cin % 64 == 0 and w.shape[1] == 9 * cin
     xi = x.float().permute(0, 3, 1, 2)
     if upsample:
         xi = F.interpolate(xi, scale_factor=2, mode="nearest")
     wk = w.float().view(-1, 3, 3, cin).permute(0, 3, 1, 2)
-    y = F.conv2d(xi, wk, None, stride=stride, padding=1)
+    if pad_br_only:
+        y = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wk, None, stride=stride, padding=0)
+    else:
+        y = F.conv2d(xi, wk, None, stride=stride, padding=1)
     N = w.shape[0]
     acc = y.permute(0, 2, 3, 1).reshape(-1, N)
     _epilogue(acc, acc.shape[0], N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32,

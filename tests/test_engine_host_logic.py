@@ -217,3 +217,31 @@ def test_vae_decoder_orchestration_vs_restatement(monkeypatch):
     err = rel_l2(out, ref)
     print(f"vae decode (emulated kernels) vs restatement: {err:.2e}")
     assert err < 3e-3
+
+
+def test_vae_encoder_orchestration_vs_restatement(monkeypatch):
+    """VAE encode engine (emulated kernels) vs oracle/vae_ref.py.  Parity with diffusers is UNPINNED."""
+    from oracle import vae_ref as V
+    from seva import _vae_engine, synthetic as synth
+    from seva.modules.autoencoder import VaeWeights
+    monkeypatch.setattr(_vae_engine, "ops", fake_ops)
+    monkeypatch.setattr(_vae_engine, "require_cuda", lambda *a: None)
+    monkeypatch.setattr(_vae_engine.VaeEncoderEngine, "_resolve_device", staticmethod(lambda w: torch.device("cpu")))
+    full = {k: tuple(v.shape) for k, v in VaeWeights().state_dict().items()}
+    assert full == {**V.decoder_shapes(), **V.encoder_shapes()}
+    small = (64, 64, 128, 128)
+    wts = VaeWeights(block_out=small)
+    shapes = {**V.decoder_shapes(block_out=small), **V.encoder_shapes(block_out=small)}
+    assert {k: tuple(v.shape) for k, v in wts.state_dict().items()} == shapes
+    sd = synth.synth_state_dict(shapes, 5)
+    wts.load_state_dict(sd)
+    eng = _vae_engine.VaeEncoderEngine(wts)
+    x = torch.rand(2, 3, 48, 64, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    out = eng.encode(x, 0.18215)
+    ref = V.vae_encode(sd, x)
+    assert out.shape == (2, 4, 6, 8)
+    err = rel_l2(out, ref)
+    print(f"vae encode (emulated kernels) vs restatement: {err:.2e}")
+    assert err < 3e-3
+    with pytest.raises(ValueError):
+        eng.encode(torch.zeros(1, 3, 20, 16), 0.18215)

@@ -263,11 +263,11 @@ def test_full_sampler_loop_vs_golden(dev, full):
 def _vae(dev, block_out, seed=3):
     from oracle import vae_ref as V
     from seva import synthetic as synth
-    from seva.modules.autoencoder import AutoEncoder, VaeDecoderWeights
+    from seva.modules.autoencoder import AutoEncoder, VaeWeights
     ae = AutoEncoder(chunk_size=1)
     if tuple(block_out) != tuple(ae.module.block_out):
-        ae.module = VaeDecoderWeights(block_out=block_out)
-    sd = synth.synth_state_dict(V.decoder_shapes(block_out=block_out), seed)
+        ae.module = VaeWeights(block_out=block_out)
+    sd = synth.synth_state_dict({**V.decoder_shapes(block_out=block_out), **V.encoder_shapes(block_out=block_out)}, seed)
     ae.module.load_state_dict(sd)
     return ae.to(dev), sd
 
@@ -372,3 +372,31 @@ def test_headline_sampler_step_finite_and_replayable(dev, full):
     lat = cond["replace"][0:1, :4]
     expect = x[0:1] + (sigmas[1] - (sigmas[0] + 1e-6)) * (x[0:1] - lat) / (sigmas[0] + 1e-6)
     assert (x1[0:1] - expect).abs().max() < 0.35 * float(x1[0:1].abs().max())
+
+
+# ------------------------------------------------------------------ VAE encoder (parity UNPINNED)
+@pytest.mark.parametrize("block_out,n,h,w", [((64, 64, 128, 128), 2, 48, 64), ((128, 256, 512, 512), 1, 128, 128)])
+def test_vae_encode_vs_restatement(dev, block_out, n, h, w):
+    """HIP encoder vs oracle/vae_ref.py (restatement of the published SD-2.1 VAE topology; self-consistency)."""
+    from oracle import vae_ref as V
+    ae, sd = _vae(dev, block_out)
+    x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    out = ae.encode(x.to(dev))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = V.vae_encode(sd, x)
+    assert out.shape == (n, 4, h // 8, w // 8)
+    err = rel_l2(out.cpu(), ref)
+    print(f"vae encode {block_out} {n}x{h}x{w}: rel-L2 {err:.3e}")
+    assert err < 2e-3
+
+
+def test_vae_encode_576_frame_and_chunking(dev):
+    """576x576 frames through the full-width encoder; chunked encode == per-frame encode (bitwise)."""
+    ae, _ = _vae(dev, (128, 256, 512, 512))
+    x = (torch.rand(2, 3, 576, 576, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(dev)
+    z = ae.encode(x, 1)
+    assert z.shape == (2, 4, 72, 72) and torch.isfinite(z).all()
+    z0 = ae.encode(x[:1], 1)
+    assert torch.equal(z[:1], z0)
+    img = ae.decode(z, 1)
+    assert img.shape == (2, 3, 576, 576) and torch.isfinite(img).all()

@@ -137,6 +137,21 @@ CONV_CASES = [  # n, ih, iw, cin, cout, stride, upsample
 ]
 
 
+@pytest.mark.parametrize("n,ih,iw,cin,cout", [(2, 16, 12, 64, 64), (1, 10, 14, 128, 96)])
+def test_conv3x3_stride2_bottom_right_padding(dev, n, ih, iw, cin, cout):
+    """diffusers Downsample2D: F.pad(x, (0,1,0,1)) then conv3x3 stride 2 padding 0."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    x = _ints((n, cin, ih, iw), -3, 3, dev, 41)
+    w = _ints((cout, cin, 3, 3), -2, 2, dev, 42)
+    b = _ints((cout,), -4, 4, dev, 43)
+    oh, ow = ih // 2, iw // 2
+    out = torch.full((n, oh * ow, cout), float("nan"), device=dev)
+    ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w), stride=2, pad_br_only=True, bias=b, out_f32=out)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    assert torch.equal(out.view(n, oh, ow, cout).permute(0, 3, 1, 2), ref)
+
+
 @pytest.mark.parametrize("n,ih,iw,cin,cout,stride,up", CONV_CASES)
 def test_conv3x3(dev, n, ih, iw, cin, cout, stride, up):
     from seva import ops
