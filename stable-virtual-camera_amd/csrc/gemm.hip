@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
   };
 
+  int st_ky = 0, st_kx = 0, st_ci0 = 0;  // MODE 1: tap / channel position of the next K-tile to stage
   auto stage = [&](int buf, int kt) {
     char* const la = lds_a + buf * A_BYTES + wave * (BM / 4) * 128;
     char* const lb = lds_b + buf * B_BYTES + wave * (BN / 4) * 128;
@@ -140,10 +141,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         for (int i = 0; i < A_PASSES; ++i) glds16(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
       }
     } else {
-      const int k0 = kt * BK;
-      const int tap = k0 / p.cin;  // block-uniform: a K-tile never straddles taps (cin % 64 == 0)
-      const int ci0 = k0 - tap * p.cin;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      // K-tiles are staged in order 0, 1, 2, ...: the (tap row, tap column, channel offset) of the tile being
+      // staged is a running scalar state (two integer divisions per K-tile otherwise, emulated on the VALU).
+      // block-uniform: a K-tile never straddles taps (cin % 64 == 0)
+      if (kt == 0) st_ky = st_kx = st_ci0 = 0;
+      const int ky = st_ky, kx = st_kx, ci0 = st_ci0;
+      st_ci0 += BK;
+      if (st_ci0 == p.cin) {
+        st_ci0 = 0;
+        if (++st_kx == 3) {
+          st_kx = 0;
+          ++st_ky;
+        }
+      }
       const int eh = p.upsample ? 2 * p.ih : p.ih, ew = p.upsample ? 2 * p.iw : p.iw;
 #pragma unroll
       for (int i = 0; i < A_PASSES; ++i) {
