@@ -7,6 +7,8 @@
 // The input may be the channel concatenation of two tensors (UNet skip concat), read in place.
 #include "seva_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int GN_THREADS = 256;
@@ -27,6 +29,8 @@ struct GnArgs {
   float* ws;
   int32_t n, hw, c1, c2, groups, dense_c, silu;
   int32_t nslab_stats;  // slabs used by the statistics pass
+  int32_t qpb;          // apply pass, channel-split mode: quads per block (gridDim.z > 1)
+  int64_t final_off;    // float offset of the finalised (mean, rstd) table inside the workspace
   float eps;
 };
 
@@ -90,6 +94,27 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(GnArgs p) {
   }
 }
 
+// Slab partials -> (mean, rstd) per (sample, group), once, in fp64, in slab order (deterministic).  Stored behind the
+// slab area of the workspace (the statistics pass uses at most GN_MAX_SLABS - 1 of the 64 slab slots per sample).
+__global__ void gn_finalize_kernel(GnArgs p) {
+  const int n = blockIdx.x, g = threadIdx.x;
+  if (g >= p.groups) return;
+  const int C = p.c1 + p.c2, cpg = C / p.groups;
+  double s = 0.0, ss = 0.0;
+  for (int sl = 0; sl < p.nslab_stats; ++sl) {
+    const float* o = p.ws + (((int64_t)n * p.nslab_stats + sl) * p.groups + g) * 2;
+    s += (double)o[0];
+    ss += (double)o[1];
+  }
+  const double cnt = (double)cpg * (double)p.hw;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float* f = p.ws + p.final_off + ((int64_t)n * p.groups + g) * 2;
+  f[0] = (float)mean;
+  f[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+}
+
 template <bool DENSE>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   __shared__ float g_mean[GN_MAX_GROUPS], g_rstd[GN_MAX_GROUPS];
@@ -99,33 +124,25 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   // thread -> (pixel lane, quad): narrow tensors pack several pixels per block, wide ones are split
   // over gridDim.z (256 quads per block); every thread owns exactly one quad of channels
   const int cq = C >> 2;
+  // the host sizes the block to the channel count: blockDim.x = pl_count * cq threads when a row of quads fits
+  // (several pixels per block), otherwise the quads are split evenly over gridDim.z blocks of p.qpb threads
   int pl, pl_count, q;
   bool active;
-  if (cq <= GN_THREADS) {
-    pl_count = GN_THREADS / cq;
+  if (gridDim.z == 1) {
+    pl_count = blockDim.x / cq;
     pl = threadIdx.x / cq;
     q = threadIdx.x - pl * cq;
     active = pl < pl_count;
   } else {
     pl_count = 1;
     pl = 0;
-    q = blockIdx.z * GN_THREADS + threadIdx.x;
-    active = q < cq;
+    q = blockIdx.z * p.qpb + threadIdx.x;
+    active = (int)threadIdx.x < p.qpb && q < cq;
   }
   if ((int)threadIdx.x < p.groups) {
-    const int g = threadIdx.x;
-    double s = 0.0, ss = 0.0;
-    for (int sl = 0; sl < p.nslab_stats; ++sl) {
-      const float* o = p.ws + (((int64_t)n * p.nslab_stats + sl) * p.groups + g) * 2;
-      s += (double)o[0];
-      ss += (double)o[1];
-    }
-    const double cnt = (double)cpg * (double)p.hw;
-    const double mean = s / cnt;
-    double var = ss / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    g_mean[g] = (float)mean;
-    g_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float* f = p.ws + p.final_off + ((int64_t)n * p.groups + threadIdx.x) * 2;
+    g_mean[threadIdx.x] = f[0];
+    g_rstd[threadIdx.x] = f[1];
   }
   __syncthreads();
   if (!active) return;
@@ -134,24 +151,48 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   const int dc = DENSE ? p.dense_c : 0;
   {
     const int c0 = q * 4;
-    float a[4], b[4], wsc[4][GN_MAX_DENSE], wsh[4][GN_MAX_DENSE], bsc[4], bsh[4];
+    // modulation weights as (scale, shift) PAIRS: one v_pk_fma_f32 per (channel, Pluecker component) instead of two
+    // v_fma_f32; the "1 +" of (1 + scale) is folded into the pair's bias
+    float a[4], b[4];
+    f32x2 wmod[4][GN_MAX_DENSE], bmod[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = c0 + r, g = c / cpg;
       a[r] = g_rstd[g] * p.gamma[c];
       b[r] = p.beta[c] - g_mean[g] * a[r];
-      bsc[r] = dc ? p.dense_b[c] : 0.f;
-      bsh[r] = dc ? p.dense_b[C + c] : 0.f;
+      bmod[r] = f32x2{1.0f + (dc ? p.dense_b[c] : 0.f), dc ? p.dense_b[C + c] : 0.f};
 #pragma unroll
-      for (int j = 0; j < GN_MAX_DENSE; ++j) {  // branch-free: clamped index, then select
-        const int jj = j < dc ? j : (dc > 0 ? dc - 1 : 0);
-        const float w0 = DENSE ? p.dense_w[(int64_t)c * dc + jj] : 0.f;
-        const float w1 = DENSE ? p.dense_w[(int64_t)(C + c) * dc + jj] : 0.f;
-        wsc[r][j] = j < dc ? w0 : 0.f;
-        wsh[r][j] = j < dc ? w1 : 0.f;
-      }
+      for (int j = 0; j < GN_MAX_DENSE; ++j) wmod[r][j] = f32x2{0.f, 0.f};
     }
-    constexpr int U = DENSE ? 1 : 2;  // pixels in flight per thread (register budget)
+    if (DENSE && dc == 6) {
+      // Pluecker modulation (6 components): the thread's 4 channels x 6 weights are 24 consecutive floats of the
+      // scale half and 24 of the shift half: 2 x 6 coalesced 16-byte loads instead of 48 scalar ones
+      f32x4 ws4[6], wh4[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        ws4[t] = *(const f32x4*)(p.dense_w + (int64_t)c0 * 6 + 4 * t);
+        wh4[t] = *(const f32x4*)(p.dense_w + (int64_t)(C + c0) * 6 + 4 * t);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int e = 6 * r + j;
+          wmod[r][j] = f32x2{ws4[e >> 2][e & 3], wh4[e >> 2][e & 3]};
+        }
+    } else if (DENSE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < GN_MAX_DENSE; ++j) {  // branch-free: clamped index, then select
+          const int c = c0 + r;
+          const int jj = j < dc ? j : (dc > 0 ? dc - 1 : 0);
+          const float w0 = p.dense_w[(int64_t)c * dc + jj];
+          const float w1 = p.dense_w[(int64_t)(C + c) * dc + jj];
+          wmod[r][j] = f32x2{j < dc ? w0 : 0.f, j < dc ? w1 : 0.f};
+        }
+    }
+    constexpr int U = 2;  // pixels in flight per thread
     for (int pix0 = p_begin + pl; pix0 < p_end; pix0 += U * pl_count) {
       f32x4 v[U];
       float dn[U][GN_MAX_DENSE];
@@ -175,13 +216,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
           float y = v[u][r] * a[r] + b[r];
           if (p.silu) y = silu_f(y);
           if (dc) {
-            float sc = bsc[r], sh = bsh[r];
+            f32x2 m = bmod[r];  // (1 + scale, shift)
 #pragma unroll
-            for (int j = 0; j < GN_MAX_DENSE; ++j) {
-              sc += wsc[r][j] * dn[u][j];
-              sh += wsh[r][j] * dn[u][j];
-            }
-            y = y * (1.0f + sc) + sh;
+            for (int j = 0; j < GN_MAX_DENSE; ++j)
+              m = __builtin_elementwise_fma(wmod[r][j], f32x2{dn[u][j], dn[u][j]}, m);
+            y = y * m[0] + m[1];
           }
           h[r] = (half_t)y;
         }
@@ -306,12 +345,21 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   const int plc = nthreads / tpp;
   // the statistics partition depends on the per-sample shape only (never on n): a sample's result
   // is bit-identical whatever else is in the batch
-  a.nslab_stats = clampi(d->hw / (plc * 16), 1, GN_MAX_SLABS);
+  a.nslab_stats = clampi(d->hw / (plc * 16), 1, GN_MAX_SLABS - 1);
+  a.final_off = (int64_t)d->n * (GN_MAX_SLABS - 1) * d->groups * 2;
+  // apply pass: block = whole pixels' worth of quads (cq <= 256: floor(256/cq) pixels per block, no idle tail
+  // beyond the last partial wave) or an even split of the quads over gridDim.z blocks
   const int plc_apply = cq <= GN_THREADS ? GN_THREADS / cq : 1;
   const int zchunks = cq <= GN_THREADS ? 1 : (cq + GN_THREADS - 1) / GN_THREADS;
-  // the modulated variant loads ~56 per-channel constants per thread: give each thread >= ~96 pixels
-  const int min_iter = d->dense ? 96 : 4;
-  const int nslab_apply = clampi(4096 / (d->n * zchunks), 1, clampi(d->hw / (min_iter * plc_apply), 1, 1024));
+  a.qpb = (cq + zchunks - 1) / zchunks;
+  int apply_threads = zchunks == 1 ? plc_apply * cq : a.qpb;
+  if (apply_threads < 64) apply_threads = 64;  // the statistics prologue needs >= `groups` (<= 64) threads
+  // pixels per thread: the modulated variant sets up 12 + 4 vector loads of per-channel constants per thread; sweep
+  // at the headline shapes (tools/kbench.py norm, SEVA_GN_MIN_ITER): 24 is best at every level (ds1 190, ds2 117,
+  // ds4 68 us; 96 left ds2 / ds4 at 158 / 97 us with 1-3 workgroups per CU)
+  int min_iter = d->dense ? 24 : 4;
+  if (const char* e = getenv("SEVA_GN_MIN_ITER")) min_iter = atoi(e) > 0 ? atoi(e) : min_iter;
+  const int nslab_apply = clampi(8192 / (d->n * zchunks), 1, clampi(d->hw / (min_iter * plc_apply), 1, 1024));
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)d->n * d->hw * C * (4.0 + 4.0 + 2.0);
   SevaProfScope prof(3, bytes, s);
@@ -319,10 +367,13 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(nthreads), lds, s, a);
   int rc = seva_check_launch("gn_stats_kernel");
   if (rc) return rc;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->n), dim3(64), 0, s, a);
+  rc = seva_check_launch("gn_finalize_kernel");
+  if (rc) return rc;
   if (d->dense)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nslab_apply, d->n, zchunks), dim3(GN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nslab_apply, d->n, zchunks), dim3(GN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
   return seva_check_launch("gn_apply_kernel");
 }
 
