@@ -131,6 +131,10 @@ typedef struct seva_groupnorm_desc {
   float* workspace;
   int32_t n, hw, c1, c2, groups, dense_c, silu;
   float eps;
+  /* optional second output: the un-normalised (concatenated) input cast to f16, [n][hw][c1+c2] -- the A operand of
+   * the ResBlock's 1x1 skip convolution (seva/modules/layers.py:137), written in the same pass instead of by a
+   * separate seva_cast_concat_f16 read of both sources.  NULL = off. */
+  void* raw_f16;
 } seva_groupnorm_desc;
 int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
 

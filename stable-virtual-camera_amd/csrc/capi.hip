@@ -58,7 +58,7 @@ SevaProfScope::~SevaProfScope() {
 extern "C" {
 
 const char* seva_last_error(void) { return g_err; }
-int seva_abi_version(void) { return 3; }
+int seva_abi_version(void) { return 4; }
 const char* seva_target_arch(void) { return "gfx950"; }
 
 int seva_graph_begin(seva_stream_t stream) {

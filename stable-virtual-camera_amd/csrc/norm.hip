@@ -26,6 +26,7 @@ struct GnArgs {
   const float* dense_w;
   const float* dense_b;
   half_t* out;
+  half_t* raw_out;  // optional: plain f16 copy of the (concatenated) input, same layout as out
   float* ws;
   int32_t n, hw, c1, c2, groups, dense_c, silu;
   int32_t nslab_stats;  // slabs used by the statistics pass
@@ -224,7 +225,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
           }
           h[r] = (half_t)y;
         }
-        if (pix < p_end) *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+        if (pix < p_end) {
+          *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+          if (p.raw_out) {  // the un-normalised input as f16: A operand of the ResBlock's 1x1 skip conv
+            const half4_t hr = {(half_t)v[u][0], (half_t)v[u][1], (half_t)v[u][2], (half_t)v[u][3]};
+            *(half4_t*)(p.raw_out + ((int64_t)n * p.hw + pix) * C + c0) = hr;
+          }
+        }
       }
     }
   }
@@ -335,7 +342,7 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   GnArgs a{};
   a.x1 = d->x1; a.x2 = d->x2; a.gamma = d->gamma; a.beta = d->beta;
   a.dense = d->dense; a.dense_w = d->dense_w; a.dense_b = d->dense_b;
-  a.out = (half_t*)d->out_f16; a.ws = d->workspace;
+  a.out = (half_t*)d->out_f16; a.raw_out = (half_t*)d->raw_f16; a.ws = d->workspace;
   a.n = d->n; a.hw = d->hw; a.c1 = d->c1; a.c2 = d->c2; a.groups = d->groups;
   a.dense_c = d->dense_c; a.silu = d->silu; a.eps = d->eps;
   const int cq = C / 4;

@@ -227,8 +227,11 @@ class SevaEngine:
         W, pfx, hw = self.W, spec.prefix, h * w
         cin, cout = spec.cin, spec.cout
         a16 = self._buf("gn16", (n, hw, cin), F16)
+        # the 1x1 skip conv (cin != cout) consumes the raw input as f16: emitted by the same GroupNorm pass
+        xs16 = self._buf("skip16", (n * hw, cin), F16) if cin != cout else None
         ops.groupnorm(x1, x2, W[pfx + ".in_layers.0.g"], W[pfx + ".in_layers.0.b"], a16, self.gn_ws,
-                      eps=1e-5, silu=True, dense=dense, dense_w=W[pfx + ".dense.w"], dense_b=W[pfx + ".dense.b"])
+                      eps=1e-5, silu=True, dense=dense, dense_w=W[pfx + ".dense.w"], dense_b=W[pfx + ".dense.b"],
+                      raw_f16=xs16)
         hmid = self._buf("res_mid", (n, hw, cout), F32)
         off = self.emb_off[pfx]
         ops.conv3x3(a16.view(n, h, w, cin), W[pfx + ".conv1.w"], bias=W[pfx + ".conv1.b"],
@@ -237,8 +240,6 @@ class SevaEngine:
         ops.groupnorm(hmid, None, W[pfx + ".out_layers.0.g"], W[pfx + ".out_layers.0.b"], b16, self.gn_ws,
                       eps=1e-5, silu=True)
         if cin != cout:
-            xs16 = self._buf("skip16", (n * hw, cin), F16)
-            ops.cast_concat_f16(x1, x2, xs16)
             res = self._buf("skip32", (n * hw, cout), F32)
             ops.gemm(xs16, W[pfx + ".skip.w"], bias=W[pfx + ".skip.b"], out_f32=res)
         else:

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
 
@@ -57,6 +57,7 @@ class GroupNormDesc(C.Structure):
         ("out_f16", c_void_p), ("workspace", c_void_p),
         ("n", c_int32), ("hw", c_int32), ("c1", c_int32), ("c2", c_int32),
         ("groups", c_int32), ("dense_c", c_int32), ("silu", c_int32), ("eps", c_float),
+        ("raw_f16", c_void_p),
     ]
 
 

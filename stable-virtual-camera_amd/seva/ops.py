@@ -149,8 +149,10 @@ def groupnorm(
     dense: torch.Tensor | None = None,
     dense_w: torch.Tensor | None = None,
     dense_b: torch.Tensor | None = None,
+    raw_f16: torch.Tensor | None = None,
 ) -> None:
-    """GroupNorm(+SiLU)(+Pluecker modulation) of cat(x1, x2) -> f16; x: [n, hw, c] f32."""
+    """GroupNorm(+SiLU)(+Pluecker modulation) of cat(x1, x2) -> f16; x: [n, hw, c] f32.
+    raw_f16: optional second output, cat(x1, x2) merely cast to f16 (same pass)."""
     require_cuda(x1, out_f16)
     n, hw, c1 = x1.shape
     c2 = x2.shape[2] if x2 is not None else 0
@@ -161,6 +163,8 @@ def groupnorm(
     d.n, d.hw, d.c1, d.c2, d.groups = n, hw, c1, c2, groups
     d.dense_c = dense.shape[-1] if dense is not None else 0
     d.silu, d.eps = 1 if silu else 0, eps
+    d.raw_f16 = ptr(raw_f16)
+    assert raw_f16 is None or (raw_f16.dtype == F16 and raw_f16.is_contiguous() and raw_f16.numel() == n * hw * (c1 + c2))
     assert workspace.numel() >= n * 64 * groups * 2
     check(_lib().seva_groupnorm_f16(C.byref(d), stream_ptr(x1.device)), "seva_groupnorm_f16")
 

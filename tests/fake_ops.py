@@ -81,8 +81,10 @@ def groupnorm_workspace(n, device):
 
 
 def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, silu=False,
-              dense=None, dense_w=None, dense_b=None):
+              dense=None, dense_w=None, dense_b=None, raw_f16=None):
     x = torch.cat([x1, x2], -1) if x2 is not None else x1
+    if raw_f16 is not None:
+        raw_f16.view(x.shape).copy_(x.half())
     C = x.shape[-1]
     y = F.group_norm(x.transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2)
     if silu:

@@ -340,6 +340,23 @@ GN_CASES = [  # n, hw, c1, c2, silu, dense
 ]
 
 
+def test_groupnorm_raw_f16_second_output(dev):
+    """raw_f16 = cat(x1, x2) cast to f16, written by the same pass; the normalised output is unchanged by it."""
+    from seva import ops
+    n, hw, c1, c2 = 3, 77, 64, 32
+    x1, x2 = _rand((n, hw, c1), dev, 51), _rand((n, hw, c2), dev, 52)
+    g, b = _rand((c1 + c2,), dev, 53), _rand((c1 + c2,), dev, 54)
+    dense, dw, db = _rand((n, hw, 6), dev, 55), _rand((2 * (c1 + c2), 6), dev, 56, 0.1), _rand((2 * (c1 + c2),), dev, 57, 0.1)
+    ws = ops.groupnorm_workspace(n, dev)
+    for kw in (dict(), dict(dense=dense, dense_w=dw, dense_b=db)):
+        o0 = torch.empty((n, hw, c1 + c2), device=dev, dtype=torch.float16)
+        o1, raw = torch.empty_like(o0), torch.full_like(o0, float("nan"))
+        ops.groupnorm(x1, x2, g, b, o0, ws, silu=True, **kw)
+        ops.groupnorm(x1, x2, g, b, o1, ws, silu=True, raw_f16=raw, **kw)
+        assert torch.equal(o0, o1)
+        assert torch.equal(raw, torch.cat([x1, x2], -1).half())
+
+
 @pytest.mark.parametrize("n,hw,c1,c2,silu,dense", GN_CASES)
 def test_groupnorm(dev, n, hw, c1, c2, silu, dense):
     from seva import ops
