@@ -633,12 +633,16 @@ int launch(const GemmArgs& a, hipStream_t s) {
   const bool astat_on = !(astat_env && astat_env[0] == '0');
   const bool dbg_run = getenv("SEVA_GEMM_DBG") || getenv("SEVA_GEMM_STAGGER");
   if constexpr (EPI == 1) {
-    if (astat_on && !dbg_run && a.K <= 320 && a.out_f16 && !a.out_f32) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
+    if constexpr (BM == 128) {
+      if (astat_on && !dbg_run && a.K <= 320 && a.out_f16 && !a.out_f32) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
+    }
     return launch_p<BM, BN, MODE, EPI, true>(a, s);
   } else {
     if constexpr (MODE == 0 && BN >= 128) {
       if (a.out_f16 && !a.out_f32 && !a.residual) {
-        if (astat_on && !dbg_run && a.K <= 320) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
+        if constexpr (BM == 128) {
+          if (astat_on && !dbg_run && a.K <= 320) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
+        }
         return launch_p<BM, BN, MODE, EPI, true>(a, s);
       }
     }
@@ -717,7 +721,11 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (cfg < 0) cfg = 0;
   if (cfg == 4 && !narrow) return seva_gemm_phase_launch(a, d->mode, d->epilogue, s);
   if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
-  if (d->epilogue == 1) return launch<128, 128, 0, 1>(a, s);
+  // Small problems (the ds8 level: 27 x 8 tiles of 128 rows on 512 workgroup slots) get 64-row tiles: twice the
+  // workgroups, both slots of a CU busy.  SEVA_GEMM_BM=64|128 forces the height (benchmark knob).
+  bool half_m = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
+  if (const char* e = getenv("SEVA_GEMM_BM")) half_m = atoi(e) == 64;
+  if (d->epilogue == 1) return half_m ? launch<64, 128, 0, 1>(a, s) : launch<128, 128, 0, 1>(a, s);
   // 128x160 tiles: every channel count of the network (320 .. 10240) is a multiple of 160, so no MFMA
   // column is idle (N = 320: 2 tiles instead of 3 with the last half empty), and a tile needs 10 %
   // fewer LDS-DMA bytes and fragment reads per FLOP than 128x128.  (128x64 tiles, tried earlier, were
@@ -726,8 +734,10 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (const char* e = getenv("SEVA_GEMM_BN")) wide = atoi(e) == 160;
   if (d->mode == 0) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
+    if (half_m) return wide ? launch<64, 160, 0, 0>(a, s) : launch<64, 128, 0, 0>(a, s);
     return wide ? launch<128, 160, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
   }
   if (narrow) return launch<128, 32, 1, 0>(a, s);
+  if (half_m) return wide ? launch<64, 160, 1, 0>(a, s) : launch<64, 128, 1, 0>(a, s);
   return wide ? launch<128, 160, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
 }
