@@ -101,6 +101,11 @@ class SevaEngine:
 
         self.use_graph = os.environ.get("SEVA_HIPGRAPH", "1") != "0"
         self._graphs: dict = {}
+        # frame-sliced execution of the token-wise chains at the largest level (see _slice_rows); 0 frames = off (default:
+        # measured end-to-end it does not pay, see _slice_rows)
+        self.slice_frames = int(os.environ.get("SEVA_SLICE_FRAMES", "0"))
+        self.slice_min_bytes = int(float(os.environ.get("SEVA_SLICE_MIN_MB", "96")) * (1 << 20))
+        self.slice_attn = os.environ.get("SEVA_SLICE_ATTN", "0") == "1"  # also slice LN -> QKV -> attention -> out-proj
 
     # ------------------------------------------------------------------ packing
     def _pack(self, model) -> None:
@@ -213,13 +218,36 @@ class SevaEngine:
         ops.layernorm(x, self.W[pfx + ".g"], self.W[pfx + ".b"], out)
         return out
 
-    def _ff(self, x32, ln_pfx, ff_pfx, rows, c, *, residual, out_f32=None, out_f16=None):
+    def _slice_rows(self, rows: int, c: int, unit: int) -> int:
+        """Rows per pass of a token-wise operator chain (LN -> GEMM -> ... -> GEMM).
+
+        Experiment, off by default (SEVA_SLICE_FRAMES=n enables).  At ds1 the f16 intermediates of one transformer block (LN
+        output 139 MB, QKV 418 MB, GEGLU hidden 557 MB) round-trip HBM between producer and consumer; run in slices of a few
+        frames through ONE reused slice-sized buffer they could stay in the 256 MB Infinity Cache.  In isolation the GEGLU -> FF2
+        pair gains 13 % at 6 frames per slice (927 -> 808 us, tools/kslice.py), but inside the step it does not pay: 105.2 ms
+        unsliced vs 105.4 (FF pairs only) / 106.7 ms (whole per-frame attention chain too: the sliced attention launches
+        under-fill the chip and the norms shrink).  Results are bitwise unchanged either way (every output row is computed from
+        its own input row only; tested).  `unit` = rows that must stay together (a frame)."""
+        if self.slice_frames <= 0 or rows * c * 2 < self.slice_min_bytes:
+            return rows
+        step = self.slice_frames * unit
+        return step if step < rows else rows
+
+    def _ff(self, x32, ln_pfx, ff_pfx, rows, c, *, residual, out_f32=None, out_f16=None, unit=1):
         """GEGLU feed-forward on LayerNorm(x32): reference transformer.py:18-34."""
-        a = self._ln(x32, ln_pfx, rows, c)
-        hidden = self._buf("ffh", (rows, 4 * c), F16)
-        ops.gemm(a, self.W[ff_pfx + ".w1"], bias=self.W[ff_pfx + ".b1"], out_f16=hidden, geglu=True)
-        ops.gemm(hidden, self.W[ff_pfx + ".w2"], bias=self.W[ff_pfx + ".b2"], residual=residual,
-                 out_f32=out_f32, out_f16=out_f16)
+        step = self._slice_rows(rows, c, unit)
+        a_buf = self._buf("ln16", (step, c), F16)
+        h_buf = self._buf("ffh", (step, 4 * c), F16)
+        W = self.W
+        for r0 in range(0, rows, step):
+            r1 = min(r0 + step, rows)
+            a, hidden = a_buf[: r1 - r0], h_buf[: r1 - r0]
+            ops.layernorm(x32[r0:r1], W[ln_pfx + ".g"], W[ln_pfx + ".b"], a)
+            ops.gemm(a, W[ff_pfx + ".w1"], bias=W[ff_pfx + ".b1"], out_f16=hidden, geglu=True)
+            ops.gemm(hidden, W[ff_pfx + ".w2"], bias=W[ff_pfx + ".b2"],
+                     residual=None if residual is None else residual[r0:r1],
+                     out_f32=None if out_f32 is None else out_f32[r0:r1],
+                     out_f16=None if out_f16 is None else out_f16[r0:r1])
 
     # ------------------------------------------------------------------ blocks
     def _resblock(self, spec, x1, x2, n, h, w, dense, emb_all):
@@ -254,6 +282,26 @@ class SevaEngine:
                         row_add, rpg, ldra, out_f32):
         """Attention.forward (self), reference transformer.py:59-74, + residual (+ folded attn2)."""
         W = self.W
+        c3 = 3 * c
+        if regime == "frame" and self.slice_attn and self._slice_rows(rows, c, hw) < rows:
+            # per-frame attention: the whole chain LN -> QKV -> attention -> out-projection runs a few frames at a time
+            step = self._slice_rows(rows, c, hw)
+            a_buf = self._buf("ln16", (step, c), F16)
+            qkv_buf = self._buf("qkv", (step, c3), F16)
+            att_buf = self._buf("att", (step, c), F16)
+            for r0 in range(0, rows, step):
+                r1 = min(r0 + step, rows)
+                nr, f0, nf = r1 - r0, r0 // hw, (r1 - r0) // hw
+                a, qkv, att = a_buf[:nr], qkv_buf[:nr], att_buf[:nr]
+                ops.layernorm(x32[r0:r1], W[ln_pfx + ".g"], W[ln_pfx + ".b"], a)
+                ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)
+                ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], att, nb0=nf, nb1=1, heads=heads, lq=hw, lk=hw,
+                              q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * c, 0, c),
+                              q_prescaled=True)
+                ops.gemm(att, W[at_pfx + ".out.w"], bias=W[at_pfx + ".out.b"], residual=residual[r0:r1],
+                         row_add=None if row_add is None else row_add[f0:], rows_per_group=rpg, ld_row_add=ldra,
+                         out_f32=out_f32[r0:r1])
+            return
         a = self._ln(x32, ln_pfx, rows, c)
         qkv = self._buf("qkv", (rows, 3 * c), F16)
         # softmax scale * log2(e) rides on the q third of the projection (fp32, before the single f16
@@ -261,7 +309,6 @@ class SevaEngine:
         ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)
         att = self._buf("att", (rows, c), F16)
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
-        c3 = 3 * c
         if regime == "frame":  # batch = frame, tokens = pixels
             ops.attention(q, k, v, att, nb0=n, nb1=1, heads=heads, lq=hw, lk=hw,
                           q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * c, 0, c),
@@ -329,10 +376,10 @@ class SevaEngine:
                         q_strides=(hw * c, 0, c), o_strides=(hw * c, 0, c), ctx_batch_stride=lc, out_f32=h1)
             # x = ff(norm3 x) + x
             h2 = self._buf("t_h2", (rows, c), F32)
-            self._ff(h1, b + ".norm3", b + ".ff", rows, c, residual=h1, out_f32=h2)
+            self._ff(h1, b + ".norm3", b + ".ff", rows, c, residual=h1, out_f32=h2, unit=hw)
             # ---- time-mix block on x_spatial = h2 (transformer.py:145-155) ----
             m1 = self._buf("t_m1", (rows, c), F32)
-            self._ff(h2, m + ".norm_in", m + ".ff_in", rows, c, residual=h2, out_f32=m1)
+            self._ff(h2, m + ".norm_in", m + ".ff_in", rows, c, residual=h2, out_f32=m1, unit=hw)
             m2 = self._buf("t_m2", (rows, c), F32)
             if collapse:
                 ra = ctxvec[:, self.ctx_off[m + ".attn2"]:]
@@ -350,7 +397,7 @@ class SevaEngine:
             final = i == spec.depth - 1
             nxt = None if final else self._buf("t_h", (rows, c), F32)
             last16 = self._buf("t_h16", (rows, c), F16)
-            self._ff(m2, m + ".norm3", m + ".ff", rows, c, residual=h2, out_f32=nxt, out_f16=last16)
+            self._ff(m2, m + ".norm3", m + ".ff", rows, c, residual=h2, out_f32=nxt, out_f16=last16, unit=hw)
             cur = nxt
         out = self._buf("out:" + pfx, (n, hw, c), F32)
         ops.gemm(last16, W[pfx + ".proj_out.w"], bias=W[pfx + ".proj_out.b"], residual=x.view(rows, c),

@@ -121,6 +121,26 @@ def test_engine_orchestration_odd_shapes(patched, T, h, w, lc):
     assert rel_l2(out, O.seva_forward(sd, x, t, y, dense, T)) < 2e-3
 
 
+@pytest.mark.parametrize("frames", [1, 2])
+def test_engine_frame_sliced_chains_match_unsliced(patched, frames):
+    """Frame-sliced execution of the LN -> GEMM -> ... chains (engine._slice_rows) is the same computation.  (Bitwise on
+    the GPU, tests/test_model_gpu.py; the torch-CPU emulation picks GEMM / LayerNorm kernels by row count and the differences pass through f16 roundings, so this
+    only guards against slicing the wrong rows, which would be an O(1) error.)"""
+    eng, _ = _cpu_engine()
+    g = torch.Generator().manual_seed(17)
+    T, h, w = 3, 8, 16
+    n = 2 * T
+    x, t = torch.randn(n, 11, h, w, generator=g), torch.randint(0, 1000, (n,), generator=g)
+    y, dense = torch.randn(n, 1, 1024, generator=g), torch.randn(n, 6, h, w, generator=g)
+    eng.slice_frames = 0
+    ref = eng.forward(x, None, t, y, dense, T).clone()
+    eng.slice_frames, eng.slice_min_bytes, eng.slice_attn = frames, 0, True  # force slicing at every level
+    out = eng.forward(x, None, t, y, dense, T)
+    err = rel_l2(out, ref)
+    print(f"sliced ({frames} frame) vs unsliced, emulated kernels: {err:.2e}")
+    assert err < 2e-3
+
+
 def test_sampler_host_logic_vs_golden(patched, monkeypatch):
     """Product sampler classes driven by the emulated kernels reproduce the reference loop."""
     from seva import sampling as S

@@ -152,6 +152,29 @@ def test_forward_is_deterministic_and_graph_replayable(dev, tiny):
     assert torch.equal(out, a)
 
 
+def test_frame_sliced_execution_is_bitwise_identical(dev, tiny):
+    """engine._slice_rows: running the token-wise chains a few frames at a time changes no bit of the output."""
+    net, _ = tiny
+    eng = net.engine()
+    g = torch.Generator().manual_seed(19)
+    T, h, w = 5, 16, 8
+    n = 2 * T
+    x, t = torch.randn(n, 11, h, w, generator=g).to(dev), torch.randint(0, 1000, (n,), generator=g).to(dev)
+    y, dense = torch.randn(n, 1, 1024, generator=g).to(dev), torch.randn(n, 6, h, w, generator=g).to(dev)
+    keep = (eng.slice_frames, eng.slice_min_bytes, eng.use_graph, eng.slice_attn)
+    try:
+        eng.use_graph = False
+        eng.slice_attn = True
+        eng.slice_frames = 0
+        ref = eng.forward(x, None, t, y, dense, T).clone()
+        for frames in (1, 3):
+            eng.slice_frames, eng.slice_min_bytes = frames, 0
+            out = eng.forward(x, None, t, y, dense, T)
+            assert torch.equal(out, ref), frames
+    finally:
+        eng.slice_frames, eng.slice_min_bytes, eng.use_graph, eng.slice_attn = keep
+
+
 def test_graph_replay_equals_eager(dev, tiny):
     """Engine default = hipGraph replay; must be bit-identical to the eager launch sequence, also when
     inputs change between calls (static input buffers are refreshed)."""
