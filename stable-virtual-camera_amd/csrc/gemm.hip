@@ -91,15 +91,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   // ---- staging state: lane (r = lane>>3, phys chunk = lane&7) of each 8-row wave-instruction ----
   const int sr = lane >> 3, sp = lane & 7;
   constexpr int AP = A_PASSES > 0 ? A_PASSES : 1;  // (ASTAT stages no A tile)
-  const half_t* a_ptr[AP];         // MODE 0: running source pointer
-  int a_by[AP], a_bx[AP];          // MODE 1: top-left input coords (conv-input space)
-  int64_t a_img[AP];               // MODE 1: element offset of image n
+  // MODE 0 plain GEMM; MODE 1 conv3x3 (fast gather: per-lane base pointer + 9-bit tap-validity mask, tap offsets are
+  // workgroup-uniform scalars); MODE 2 conv3x3 with the fused nearest-2x upsample (general per-tap address math)
+  const half_t* a_ptr[AP];         // MODE 0: running source pointer; MODE 1: pixel (oy*stride - pad, ox*stride - pad)
+  unsigned a_mask[AP];             // MODE 1: bit (3*ky + kx) set = tap inside the image
+  int a_by[AP], a_bx[AP];          // MODE 2: top-left input coords (conv-input space)
+  int64_t a_img[AP];               // MODE 2: element offset of image n
   int a_q[AP];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int row = wave * (BM / 4) + 8 * i + sr;  // row inside the tile
     const int q = sp ^ ((row >> 1) & 7);           // logical 16-B chunk this lane fetches
     a_q[i] = q;
+    a_mask[i] = 0;
     int64_t m = m0 + row;
     if (m >= p.M) m = p.M - 1;
     if (dbg & 4) m = row;
@@ -116,6 +120,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       a_bx[i] = ox * p.stride - p.pad_lo;
       a_img[i] = (int64_t)img * p.ih * p.iw * p.cin;
       a_ptr[i] = nullptr;
+      if (MODE == 1) {
+        // may point outside the image for border pixels: only dereferenced for taps whose mask bit is set
+        a_ptr[i] = p.a + a_img[i] + ((int64_t)a_by[i] * p.iw + a_bx[i]) * p.cin + q * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = a_by[i] + t / 3, ix = a_bx[i] + t % 3;
+          if ((iy >= 0) & (iy < p.ih) & (ix >= 0) & (ix < p.iw)) a_mask[i] |= 1u << t;
+        }
+      }
     }
   }
   const half_t* b_ptr[B_PASSES];
@@ -154,15 +167,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           ++st_ky;
         }
       }
-      const int eh = p.upsample ? 2 * p.ih : p.ih, ew = p.upsample ? 2 * p.iw : p.iw;
+      if (MODE == 1) {
+        const int64_t tap_off = ((int64_t)ky * p.iw + kx) * p.cin + ci0;  // elements, workgroup-uniform
+        const unsigned bit = 1u << (3 * ky + kx);
 #pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) {
-        const int iy = a_by[i] + ky, ix = a_bx[i] + kx;
-        const bool ok = (iy >= 0) & (iy < eh) & (ix >= 0) & (ix < ew);
-        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-        const half_t* src = p.a + a_img[i] + ((int64_t)sy * p.iw + sx) * p.cin + ci0 + a_q[i] * 8;
-        const void* g = ok ? (const void*)src : (const void*)g_zero_page;
-        glds16(g, la + i * 1024);
+        for (int i = 0; i < A_PASSES; ++i) {
+          const void* g = (a_mask[i] & bit) ? (const void*)(a_ptr[i] + tap_off) : (const void*)g_zero_page;
+          glds16(g, la + i * 1024);
+        }
+      } else {
+        const int eh = 2 * p.ih, ew = 2 * p.iw;  // MODE 2: taps index the nearest-2x upsampled image
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+          const int iy = a_by[i] + ky, ix = a_bx[i] + kx;
+          const bool ok = (iy >= 0) & (iy < eh) & (ix >= 0) & (ix < ew);
+          const int sy = iy >> 1, sx = ix >> 1;
+          const half_t* src = p.a + a_img[i] + ((int64_t)sy * p.iw + sx) * p.cin + ci0 + a_q[i] * 8;
+          const void* g = ok ? (const void*)src : (const void*)g_zero_page;
+          glds16(g, la + i * 1024);
+        }
       }
     }
 #pragma unroll
@@ -736,6 +759,11 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
     if (half_m) return wide ? launch<64, 160, 0, 0>(a, s) : launch<64, 128, 0, 0>(a, s);
     return wide ? launch<128, 160, 0, 0>(a, s) : launch<128, 128, 0, 0>(a, s);
+  }
+  if (d->upsample) {  // the three Upsample convs of a step: general gather (MODE 2)
+    if (narrow) return launch<128, 32, 2, 0>(a, s);
+    if (half_m) return wide ? launch<64, 160, 2, 0>(a, s) : launch<64, 128, 2, 0>(a, s);
+    return wide ? launch<128, 160, 2, 0>(a, s) : launch<128, 128, 2, 0>(a, s);
   }
   if (narrow) return launch<128, 32, 1, 0>(a, s);
   if (half_m) return wide ? launch<64, 160, 1, 0>(a, s) : launch<64, 128, 1, 0>(a, s);
