@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
 import torch
 from seva import ops
 dev = torch.device("cuda:0")
-SHAPES = [(217728, 960, 320, "o16"), (217728, 2560, 320, "o16"), (217728, 320, 320, "o32res"), (54432, 1920, 640, "o16")]
+SHAPES = [(13608, 1280, 5120, "o16"), (54432, 1920, 640, "o16"), (13608, 3840, 1280, "o16")]
 # 1024 = dbg build with every bit off (its codegen differs from the production instantiation)
-MODES = [(0, "prod"), (1024, "dbg build"), (256, "stores to L2-resident rows"), (64, "no epi stores"), (128, "no A dma"), (128 | 256, "no A dma + L2 stores"), (128 | 64, "no A dma, no stores")]
+MODES = [(0, "prod"), (1024, "dbg build"), (8, "no frag reads"), (1, "no dma"), (1 | 8, "mfma only"), (2 | 8, "dma only"), (2, "no mfma"), (16, "no barrier")]
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
