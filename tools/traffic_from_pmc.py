@@ -15,7 +15,7 @@ import sys
 import re
 
 # kernel names: gemm_kernel<BM, BN, MODE, EPI, DBG> (MODE 0 plain / 1 conv3x3), attn_kernel<NW, KT, ...>
-CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128), (128|160), 0, "), "conv": re.compile(r"gemm_kernel<(64|128), (128|160), 1, "),
+CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128), (128|160), 0, "), "conv": re.compile(r"gemm_kernel<(64|128), (128|160), [12], "),
            "attention": re.compile(r"attn_kernel<4, 64")}
 
 
