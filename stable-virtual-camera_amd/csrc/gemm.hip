@@ -617,6 +617,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
       if (args.tiles_n % t == 0) { per = t; break; }
     chunks = per ? args.tiles_n / per : (args.tiles_n + 3) / 4;
   }
+  if (ASTAT) chunks = 1;  // the A panel sits in registers: re-loading it per sibling is pure cost (re-swept: c1 best)
   if (chunks < base) {
     chunks = base;
     for (int c = base; c <= 2 * base && c <= args.tiles_n; ++c)  // nearest even split above `base`
