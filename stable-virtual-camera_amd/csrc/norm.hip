@@ -98,15 +98,21 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(GnArgs p) {
 // Slab partials -> (mean, rstd) per (sample, group), once, in fp64, in slab order (deterministic).  Stored behind the
 // slab area of the workspace (the statistics pass uses at most GN_MAX_SLABS - 1 of the 64 slab slots per sample).
 __global__ void gn_finalize_kernel(GnArgs p) {
-  const int n = blockIdx.x, g = threadIdx.x;
-  if (g >= p.groups) return;
+  // one wave per (sample, group): lane l takes slab l (nslab_stats <= 63), then a fixed xor-shuffle tree in fp64
+  const int n = blockIdx.x, g = blockIdx.y, l = threadIdx.x;
   const int C = p.c1 + p.c2, cpg = C / p.groups;
   double s = 0.0, ss = 0.0;
-  for (int sl = 0; sl < p.nslab_stats; ++sl) {
-    const float* o = p.ws + (((int64_t)n * p.nslab_stats + sl) * p.groups + g) * 2;
-    s += (double)o[0];
-    ss += (double)o[1];
+  if (l < p.nslab_stats) {
+    const float* o = p.ws + (((int64_t)n * p.nslab_stats + l) * p.groups + g) * 2;
+    s = (double)o[0];
+    ss = (double)o[1];
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    ss += __shfl_xor(ss, off, 64);
+  }
+  if (l != 0) return;
   const double cnt = (double)cpg * (double)p.hw;
   const double mean = s / cnt;
   double var = ss / cnt - mean * mean;
@@ -374,7 +380,7 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(nthreads), lds, s, a);
   int rc = seva_check_launch("gn_stats_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->n), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->n, d->groups), dim3(64), 0, s, a);
   rc = seva_check_launch("gn_finalize_kernel");
   if (rc) return rc;
   if (d->dense)
