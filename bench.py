@@ -89,12 +89,12 @@ def make_sampler(net, device, T, hw, steps, seed):
 
 def cpu_baseline(sd):
     """CPU oracle (restatement pinned to the reference, oracle/) on BASELINE config 1:
-    T=4, 32x32 latent, CFG batch 8 -- bounded sample: 2 sampler steps."""
+    T=4, 32x32 latent, CFG batch 8 -- bounded sample: 4 sampler steps (about 15 s on 16 host threads)."""
     from oracle import sampling_ref as SR
     from oracle import seva_ref as OR
     from seva import synthetic as synth
 
-    T, hw, steps = 4, 32, 2
+    T, hw, steps = 4, 32, 4
     sc = synth.synth_scene(T, (hw, hw), (0,), seed=23)
     net = lambda x, idx, c, num_frames: OR.sgm_wrapper_forward(sd, x, idx, c, num_frames)  # noqa: E731
     try:
