@@ -131,16 +131,39 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   // lane (r = lane>>3, physical chunk = lane&7) of each 8-row wave-instruction; the swizzle is applied
   // on the SOURCE chunk (the LDS image of an LDS-DMA is lane-linear)
   const int sr = lane >> 3, sp = lane & 7;
+  // Tiles are issued strictly in order 0, 1, 2, ...: the per-lane source pointers of the NEXT tile to issue are
+  // running state, advanced by the workgroup-uniform tile stride (the 64-bit key * stride products cost four
+  // quarter-rate v_mul_lo_u32 / two v_mad_u64_u32 per tile in a VALU-bound kernel).  Only a partial last tile
+  // recomputes its addresses, to clamp the rows past lk onto the last key.
+  const half_t* kp[IP];
+  const half_t* vp[IP];
+#pragma unroll
+  for (int i = 0; i < IP; ++i) {
+    const int row = 8 * (wave_u * IP + i) + sr;
+    const int key = row < p.lk ? row : p.lk - 1;
+    kp[i] = kbase + (int64_t)key * p.k_sl + k_chunk_swz(row, sp) * 8;
+    vp[i] = vbase + (int64_t)key * p.k_sl + v_chunk_swz(row, sp) * 8;
+  }
+  const int64_t tile_stride = (int64_t)KT * p.k_sl;
+  const bool ragged = (p.lk % KT) != 0;
   auto issue_tile = [&](int kt, int buf) {
+    const bool clamp = ragged && kt == nt - 1 && kt > 0;  // (tile 0 was clamped when the pointers were built)
 #pragma unroll
     for (int i = 0; i < IP; ++i) {
-      const int row = 8 * (wave_u * IP + i) + sr;
-      int key = kt * KT + row;
-      if (key >= p.lk) key = p.lk - 1;
-      const int64_t roff = (int64_t)key * p.k_sl;
       const unsigned dst = smem_base + buf * BUF_BYTES + 8 * (wave_u * IP + i) * 128;
-      glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
-      glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
+      if (clamp) {
+        const int row = 8 * (wave_u * IP + i) + sr;
+        int key = kt * KT + row;
+        if (key >= p.lk) key = p.lk - 1;
+        const int64_t roff = (int64_t)key * p.k_sl;
+        glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
+        glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
+      } else {
+        glds16_raw(kp[i], dst);
+        glds16_raw(vp[i], dst + KT * 128);
+      }
+      kp[i] += tile_stride;
+      vp[i] += tile_stride;
     }
   };
 
