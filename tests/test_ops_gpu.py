@@ -78,6 +78,46 @@ def test_gemm_tile_width_knob_exact(dev, M, N, K, bn, monkeypatch):
     assert torch.equal(o32, a @ w.T + bias + res)
 
 
+@pytest.mark.parametrize("astat", ["0", "1"])
+@pytest.mark.parametrize("M,N,K", [(300, 960, 320), (1000, 1920, 640), (515, 640, 192), (257, 2560, 320)])
+def test_gemm_f16_only_multi_tile_walk_exact(dev, M, N, K, astat, monkeypatch):
+    """f16-only outputs take the ASYNC schedule (next-tile stages issued before the epilogue, counted vmcnt leaves the
+    stores in flight) and, for K <= 320, the A-in-registers variant.  One workgroup per M-tile (SEVA_GEMM_CHUNKS=1)
+    makes it walk every N-tile, so the cross-tile bookkeeping is exercised; exact on integers, with bias, column
+    scale and ragged M."""
+    from seva import ops
+    monkeypatch.setenv("SEVA_GEMM_CHUNKS", "1")
+    monkeypatch.setenv("SEVA_GEMM_ASTAT", astat)
+    a = _ints((M, K), -4, 4, dev, 61)
+    w = _ints((N, K), -3, 3, dev, 62)
+    bias = _ints((N,), -5, 5, dev, 63)
+    o16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    for _ in range(3):  # back-to-back launches: stores of one launch in flight under the next
+        ops.gemm(a.half(), w.half(), bias=bias, out_f16=o16, col_scale=0.5, col_scale_n=N // 4 // 4 * 4)
+    ref = a @ w.T + bias
+    ref[:, : N // 4 // 4 * 4] *= 0.5
+    torch.cuda.synchronize()
+    assert torch.equal(o16.float(), ref.half().float())
+
+
+@pytest.mark.parametrize("astat", ["0", "1"])
+@pytest.mark.parametrize("M,C,K", [(300, 320, 320), (1000, 640, 640)])
+def test_geglu_multi_tile_walk(dev, M, C, K, astat, monkeypatch):
+    from seva import ops
+    from seva._engine import interleave_geglu
+    monkeypatch.setenv("SEVA_GEMM_CHUNKS", "1")
+    monkeypatch.setenv("SEVA_GEMM_ASTAT", astat)
+    a = _rand((M, K), dev, 71).half()
+    w = (_rand((8 * C, K), dev, 72) * K ** -0.5).half()
+    b = _rand((8 * C,), dev, 73)
+    wi, bi = interleave_geglu(w, b)
+    o16 = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.float16)
+    ops.gemm(a, wi, bias=bi, out_f16=o16, geglu=True)
+    y = a.float() @ w.float().T + b
+    ref = y[:, : 4 * C] * F.gelu(y[:, 4 * C:])
+    assert torch.isfinite(o16).all() and rel_l2(o16, ref) < 1e-3
+
+
 @pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 4, 64), (777, 960, 640), (4097, 132, 192)])
 def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg):
