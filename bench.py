@@ -161,6 +161,8 @@ def main():
     with torch.no_grad():
         for i in range(Wm):
             x = step(i, x)
+        if world > 1:
+            exchange_anchor_latents(anchors)  # untimed: first use of the all-gather (RCCL sets channels up lazily)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
