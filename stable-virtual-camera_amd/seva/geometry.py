@@ -31,7 +31,13 @@ def _reexport_reference() -> None:
         return
     spec = importlib.util.spec_from_file_location("seva._reference_geometry", path)
     mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    try:
+        spec.loader.exec_module(mod)
+    except ImportError as e:  # e.g. the reference's own dependency `roma` is not installed
+        import warnings
+
+        warnings.warn(f"seva.geometry: could not re-export the reference's geometry helpers from {path}: {e}")
+        return
     for name in dir(mod):
         if not name.startswith("_"):
             globals().setdefault(name, getattr(mod, name))
