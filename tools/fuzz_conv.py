@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Randomised exactness fuzz of the implicit-GEMM 3x3 conv (integer data): sizes, stride 1/2, fused nearest-2x upsample,
+bottom/right-only padding, residual / row_add, tile shapes."""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
+import torch
+import torch.nn.functional as F
+from seva import ops
+from seva._engine import pack_conv3x3
+dev = torch.device("cuda:0")
+rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+def ints(shape, lo, hi):
+    return torch.randint(lo, hi + 1, shape, generator=g).float().to(dev)
+bad = 0
+for case in range(ncases):
+    n = rng.choice([1, 2, 3, 5])
+    ih, iw = rng.choice([4, 5, 8, 9, 16, 33]), rng.choice([4, 6, 7, 12, 16, 31])
+    cin, cout = 64 * rng.choice([1, 2, 3]), rng.choice([4, 64, 96, 160, 320])
+    mode = rng.choice(["s1", "s1", "s2", "up", "s2br"])
+    if mode == "s2br" and (ih % 2 or iw % 2):
+        mode = "s2"
+    for k, vals in (("SEVA_GEMM_BN", [None, "128", "160"]), ("SEVA_GEMM_BM", [None, "64", "128"]), ("SEVA_GEMM_CHUNKS", [None, "1", "2"])):
+        v = rng.choice(vals)
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
+    x, w, b = ints((n, cin, ih, iw), -3, 3), ints((cout, cin, 3, 3), -2, 2), ints((cout,), -4, 4)
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
+    if mode == "s2br":
+        ref = F.conv2d(F.pad(xi, (0, 1, 0, 1)), w, b, stride=2)
+    else:
+        ref = F.conv2d(xi, w, b, stride=2 if mode == "s2" else 1, padding=1)
+    oh, ow = ref.shape[-2:]
+    res = ints((n, oh * ow, cout), -9, 9) if rng.random() < 0.5 else None
+    radd = ints((n, cout), -3, 3) if rng.random() < 0.5 else None
+    out = torch.full((n, oh * ow, cout), float("nan"), device=dev)
+    ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w), stride=2 if mode in ("s2", "s2br") else 1,
+                upsample=mode == "up", pad_br_only=mode == "s2br", bias=b, residual=res, row_add=radd,
+                rows_per_group=oh * ow if radd is not None else 0, out_f32=out)
+    refl = ref.permute(0, 2, 3, 1).reshape(n, oh * ow, cout)
+    if radd is not None: refl = refl + radd[:, None, :]
+    if res is not None: refl = refl + res
+    torch.cuda.synchronize()
+    if not torch.equal(out, refl):
+        bad += 1
+        print("MISMATCH", case, n, ih, iw, cin, cout, mode, {k: os.environ.get(k) for k in ("SEVA_GEMM_BN", "SEVA_GEMM_BM", "SEVA_GEMM_CHUNKS")}, flush=True)
+print(f"conv fuzz: {ncases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Randomised exactness fuzz of seva_gemm_f16 (integer data => every path must be bit-exact): random M/N/K, output
+kinds, residual / row_add / column scale, forced chunk counts, tile widths and heights, A-in-registers on/off."""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
+import torch
+from seva import ops
+dev = torch.device("cuda:0")
+rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+def ints(shape, lo, hi):
+    return torch.randint(lo, hi + 1, shape, generator=g).float().to(dev)
+bad = 0
+for case in range(ncases):
+    M = rng.choice([1, 7, 64, 127, 128, 129, 300, 777, 1025, 2049, 4100])
+    N = rng.choice([4, 36, 128, 132, 160, 320, 324, 480, 640, 960, 1280, 1924])
+    K = 64 * rng.choice([1, 2, 3, 5, 8, 10, 20])
+    kind = rng.choice(["f16", "f16", "f32", "both", "f16res", "f32res", "f16radd"])
+    for k, vals in (("SEVA_GEMM_CHUNKS", [None, "1", "2", "3", "5"]), ("SEVA_GEMM_BN", [None, "128", "160"]),
+                    ("SEVA_GEMM_BM", [None, "64", "128"]), ("SEVA_GEMM_ASTAT", [None, "0"])):
+        v = rng.choice(vals)
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
+    a, w, bias = ints((M, K), -4, 4), ints((N, K), -3, 3), ints((N,), -5, 5)
+    res = ints((M, N), -9, 9) if "res" in kind else None
+    rpg = rng.choice([1, 5, 64])
+    radd = ints(((M + rpg - 1) // rpg, N), -3, 3) if "radd" in kind else None
+    ns = 0
+    if kind == "f16" and N > 32 and rng.random() < 0.5:
+        ns = rng.randrange(0, N // 4 + 1) * 4
+    o16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16) if kind != "f32" and kind != "f32res" else None
+    o32 = torch.full((M, N), float("nan"), device=dev) if kind in ("f32", "both", "f32res") else None
+    for _ in range(2):
+        ops.gemm(a.half(), w.half(), bias=bias, residual=res, row_add=radd, rows_per_group=rpg if radd is not None else 0,
+                 out_f32=o32, out_f16=o16, col_scale=0.5 if ns else 1.0, col_scale_n=ns)
+    ref = a @ w.T + bias
+    if ns: ref[:, :ns] *= 0.5
+    if radd is not None: ref = ref + radd.repeat_interleave(rpg, 0)[:M]
+    if res is not None: ref = ref + res
+    torch.cuda.synchronize()
+    ok = (o32 is None or torch.equal(o32, ref)) and (o16 is None or torch.equal(o16.float(), ref.half().float()))
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, M, N, K, kind, ns, {k: os.environ.get(k) for k in ("SEVA_GEMM_CHUNKS", "SEVA_GEMM_BN", "SEVA_GEMM_BM", "SEVA_GEMM_ASTAT")}, flush=True)
+print(f"fuzz: {ncases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
