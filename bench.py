@@ -219,7 +219,7 @@ def main():
         # VAE decode of finished latents (reference autoencoder.py:40-48, chunk_size=1), outside `value`
         from seva.modules.autoencoder import AutoEncoder
 
-        ae = AutoEncoder(chunk_size=1).to(device)
+        ae = AutoEncoder(chunk_size=1, random_init=True).to(device)
         zl = (x[:2] / x[:2].std() * 0.18215).contiguous()
         with torch.no_grad():
             ae.decode(zl[:1])

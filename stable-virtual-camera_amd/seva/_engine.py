@@ -26,7 +26,7 @@ import math
 
 import torch
 
-from . import ops
+from . import _native, ops
 from ._arch import Layout
 from ._native import SevaNativeError, require_cuda
 
@@ -432,21 +432,34 @@ class SevaEngine:
                tuple(dense_y.shape), int(num_frames))
         ent = self._graphs.get(key)
         if ent is None:
-            st = {
-                "x": torch.empty_like(x, dtype=F32).contiguous(),
-                "concat": None if concat is None else torch.empty_like(concat, dtype=F32).contiguous(),
-                "t": torch.empty_like(t, dtype=torch.int64).contiguous(),
-                "y": torch.empty_like(y, dtype=F32).contiguous(),
-                "dense": torch.empty_like(dense_y, dtype=F32).contiguous(),
-            }
+            # static input buffers: ordinary tensors even under torch.inference_mode() (reference eval.py:1242) -- an
+            # inference tensor could not be refreshed in place by a later call made outside that mode
+            with torch.inference_mode(False):
+                st = {
+                    "x": torch.empty(x.shape, dtype=F32, device=self.device),
+                    "concat": None if concat is None else torch.empty(concat.shape, dtype=F32, device=self.device),
+                    "t": torch.empty(t.shape, dtype=torch.int64, device=self.device),
+                    "y": torch.empty(y.shape, dtype=F32, device=self.device),
+                    "dense": torch.empty(dense_y.shape, dtype=F32, device=self.device),
+                }
+                out = torch.empty((x.shape[0], self.p.out_channels) + tuple(x.shape[2:]), dtype=F32, device=self.device)
             self._copy_inputs(st, x, concat, t, y, dense_y)
-            out = self.forward(st["x"], st["concat"], st["t"], st["y"], st["dense"], num_frames)  # warm
+            self.forward(st["x"], st["concat"], st["t"], st["y"], st["dense"], num_frames, out=out)  # warm the arena
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             graph = ops.Graph()
             with torch.cuda.stream(side):
                 graph.capture_begin(self.device)
-                self.forward(st["x"], st["concat"], st["t"], st["y"], st["dense"], num_frames, out=out)
+                try:
+                    self.forward(st["x"], st["concat"], st["t"], st["y"], st["dense"], num_frames, out=out)
+                except BaseException:
+                    # leave no stream stuck in capture mode: end + discard the partial graph, then run eagerly from now on
+                    try:
+                        graph.capture_end(self.device)
+                    except Exception:
+                        pass
+                    self.use_graph = False
+                    raise
                 graph.capture_end(self.device)
             torch.cuda.current_stream(self.device).wait_stream(side)
             ent = (graph, st, out)
@@ -466,7 +479,9 @@ class SevaEngine:
         st["dense"].copy_(dense_y)
 
     def __call__(self, x, concat, t, y, dense_y, num_frames):
-        if self.use_graph:
+        # inside a whole-step capture (seva/_stepgraph.py) or its warm-up the network is launched eagerly: its ~600
+        # kernels become nodes of the step graph instead of a nested replay
+        if self.use_graph and not _native.network_eager_forced() and not torch.cuda.is_current_stream_capturing():
             return self.forward_graphed(x, concat, t, y, dense_y, num_frames)
         return self.forward(x, concat, t, y, dense_y, num_frames)
 

@@ -98,6 +98,25 @@ SYMBOLS = {
 
 _lib = None
 
+# > 0: `SevaEngine.__call__` launches the network eagerly instead of replaying its own network-only hipGraph
+# (set around the warm-up step of the whole-step graph, seva/_stepgraph.py)
+_EAGER_DEPTH = 0
+
+
+class eager_network:
+    def __enter__(self):
+        global _EAGER_DEPTH
+        _EAGER_DEPTH += 1
+
+    def __exit__(self, *exc):
+        global _EAGER_DEPTH
+        _EAGER_DEPTH -= 1
+        return False
+
+
+def network_eager_forced() -> bool:
+    return _EAGER_DEPTH > 0
+
 
 def load() -> C.CDLL:
     """Load libseva_hip.so and bind every symbol; raises SevaNativeError on any problem."""

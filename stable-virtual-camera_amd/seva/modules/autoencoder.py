@@ -3,7 +3,9 @@
 The reference delegates to `diffusers.AutoencoderKL.from_pretrained("stabilityai/stable-diffusion-2-1-base",
 subfolder="vae")` (autoencoder.py:12-17).  Neither diffusers nor the weights are available offline, so this
 module owns (a) a parameter holder with diffusers' key names (`encoder.*`, `quant_conv.*`, `post_quant_conv.*`,
-`decoder.*`), so a real `diffusion_pytorch_model.safetensors` loads with `load_state_dict(strict=False)`, and (b) the
+`decoder.*`), so a real `diffusion_pytorch_model.safetensors` loads STRICTLY (`load_vae_state_dict`: every key
+must match after the deprecated mid-block attention names `query/key/value/proj_attn` -- which diffusers itself remaps at
+load time -- are translated to `to_q/to_k/to_v/to_out.0`), and (b) the
 encode and decode paths on the HIP kernels (`seva/_vae_engine.py`).  Parity with diffusers is UNPINNED (no fixture can be made here);
 tests compare against our own restatement of the published topology.
 
@@ -15,6 +17,8 @@ as the reference does (autoencoder.py:21-25).
 from __future__ import annotations
 
 import os
+import re
+import warnings
 
 import torch
 from torch import nn
@@ -110,18 +114,67 @@ class VaeWeights(VaeDecoderWeights):
         self.put("quant_conv", nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1))
 
 
+_LEGACY_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+_LEGACY_RE = re.compile(r"^((?:encoder|decoder)\.mid_block\.attentions\.0)\.(query|key|value|proj_attn)\.(weight|bias)$")
+
+
+def remap_legacy_vae_keys(sd: dict) -> dict:
+    """Deprecated attention names of older AutoencoderKL checkpoints -> current ones (diffusers does this in
+    `_convert_deprecated_attention_blocks` when it loads such a file).  1x1-conv shaped projection weights
+    (C, C, 1, 1) become Linear weights (C, C)."""
+    out = {}
+    for k, v in sd.items():
+        m = _LEGACY_RE.match(k)
+        if m:
+            k = f"{m.group(1)}.{_LEGACY_ATTN[m.group(2)]}.{m.group(3)}"
+        if ".mid_block.attentions.0.to_" in k and k.endswith(".weight") and v.ndim == 4:
+            v = v.reshape(v.shape[0], v.shape[1])
+        if k in out:
+            raise RuntimeError(f"VAE checkpoint holds both the deprecated and the current name of {k}")
+        out[k] = v
+    return out
+
+
+def load_vae_state_dict(module: nn.Module, sd: dict) -> None:
+    """Strict load: a key that is missing or unexpected after the legacy-name translation is an error (a silent
+    `strict=False` would leave e.g. the mid-block attention on its random initialisation)."""
+    sd = remap_legacy_vae_keys(sd)
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    if missing or unexpected:
+        raise RuntimeError(
+            f"VAE checkpoint does not match the SD-2.1 AutoencoderKL layout: {len(missing)} missing "
+            f"(e.g. {list(missing)[:3]}), {len(unexpected)} unexpected (e.g. {list(unexpected)[:3]})")
+
+
 class AutoEncoder(nn.Module):
     scale_factor: float = 0.18215
     downsample: int = 8
 
-    def __init__(self, chunk_size: int | None = None):
+    def __init__(self, chunk_size: int | None = None, *, random_init: bool | None = None):
+        """`SEVA_VAE_PATH` = local `diffusion_pytorch_model.safetensors` of stabilityai/stable-diffusion-2-1-base/vae
+        (the reference downloads it, autoencoder.py:12-17; there is no network here).  Without it the module refuses to
+        run on random weights unless that is asked for explicitly (`random_init=True` or `SEVA_VAE_RANDOM_INIT=1`:
+        benchmarks and tests with synthetic weights)."""
         super().__init__()
         self.module = VaeWeights()
         path = os.environ.get("SEVA_VAE_PATH")  # local diffusers VAE safetensors, if the user has one
+        if random_init is None:
+            random_init = os.environ.get("SEVA_VAE_RANDOM_INIT", "0") == "1"
+        self.random_init = False
         if path:
             import safetensors.torch
 
-            self.module.load_state_dict(safetensors.torch.load_file(path), strict=False)
+            load_vae_state_dict(self.module, safetensors.torch.load_file(path))
+        elif random_init:
+            self.random_init = True
+            warnings.warn("seva AutoEncoder: running on RANDOM-INIT VAE weights (no SEVA_VAE_PATH): outputs are "
+                          "meaningless images / latents; fine for benchmarks and synthetic-weight tests only.",
+                          RuntimeWarning, stacklevel=2)
+        else:
+            raise RuntimeError(
+                "seva AutoEncoder: no VAE weights. Set SEVA_VAE_PATH to the SD-2.1-base VAE safetensors file "
+                "(stabilityai/stable-diffusion-2-1-base, subfolder vae), or pass random_init=True / set "
+                "SEVA_VAE_RANDOM_INIT=1 to run on random weights on purpose.")
         self.module.eval().requires_grad_(False)
         self.chunk_size = chunk_size
         self._engine = None

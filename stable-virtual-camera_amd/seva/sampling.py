@@ -23,7 +23,7 @@ import numpy as np
 import torch
 from tqdm import tqdm
 
-from . import ops
+from . import _native, _stepgraph, ops
 from ._native import SevaNativeError
 
 
@@ -278,16 +278,29 @@ class MultiviewCFG(VanillaCFG):
         self.guidance = ConstantGuidance()
         self._rule_cache: tuple | None = None
 
+    def reset_rule_cache(self) -> None:
+        """Called by `EulerEDMSampler.prepare_sampling_loop`: a new trajectory never reuses an old rule."""
+        self._rule_cache = None
+
     def _ruled_scale(self, scale, c2w, K, input_frame_mask):
-        """scale_rule(...) with its boolean-mask indexing (a host sync) paid once per trajectory."""
-        key = (
-            float(scale) if not isinstance(scale, torch.Tensor) else (scale.data_ptr(), scale._version),
-            c2w.data_ptr(), c2w._version, K.data_ptr(), K._version,
-            input_frame_mask.data_ptr(), input_frame_mask._version,
-        )
-        if self._rule_cache is None or self._rule_cache[0] != key:
-            self._rule_cache = (key, self.scale_rule(scale, c2w, K, input_frame_mask))
-        return self._rule_cache[1]
+        """scale_rule(...) with its boolean-mask indexing (a host sync) paid once per trajectory.
+
+        The cache entry keeps STRONG references to the very tensor objects it was computed from and matches by
+        object identity (`is`), so an address the caching allocator hands out again for another scene can never
+        alias an entry, and nothing here reads `_version` (inference tensors -- reference eval.py:1242 creates
+        c2w / K / mask under torch.inference_mode() -- do not track one).  `do_sample` passes the same tensor
+        objects on every step of a trajectory (eval.py:1285-1312), which is what makes the hit path the common one;
+        in-place edits of those tensors between steps are not part of the reference's contract."""
+        ent = self._rule_cache
+        if ent is not None:
+            (s0, a0, b0, m0), val = ent
+            same_scale = (s0 is scale) if isinstance(scale, torch.Tensor) else (
+                not isinstance(s0, torch.Tensor) and s0 == scale)
+            if same_scale and a0 is c2w and b0 is K and m0 is input_frame_mask:
+                return val
+        val = self.scale_rule(scale, c2w, K, input_frame_mask)
+        self._rule_cache = ((scale, c2w, K, input_frame_mask), val)
+        return val
 
     def frame_scale(self, x, sigma, scale, c2w=None, K=None, input_frame_mask=None, **_):
         return self.scale_schedule(sigma, self._ruled_scale(scale, c2w, K, input_frame_mask))
@@ -306,16 +319,30 @@ class MultiviewTemporalCFG(MultiviewCFG):
         idx = torch.arange(num_frames)
         self.distance_matrix = (idx[None] - idx[:, None]).abs()
 
-    def frame_scale(self, x, sigma, scale, c2w=None, K=None, input_frame_mask=None, **_):
+    def _ruled_scale(self, scale, c2w, K, input_frame_mask, ndim=4):
+        """Temporal ramp + close-frame rule: step-invariant, so (like MultiviewCFG) evaluated once per trajectory and
+        cached by the identity of the tensors it came from; its boolean indexing is a host sync that must not sit
+        inside a captured step."""
+        ent = self._rule_cache
+        if ent is not None:
+            (s0, a0, b0, m0), val = ent
+            same_scale = (s0 is scale) if isinstance(scale, torch.Tensor) else (
+                not isinstance(s0, torch.Tensor) and s0 == scale)
+            if same_scale and a0 is c2w and b0 is K and m0 is input_frame_mask:
+                return val
         mask = input_frame_mask.reshape(-1, self.num_frames)
         min_distance = (
-            self.distance_matrix[None].to(x.device) + (~mask[:, None]) * self.num_frames
+            self.distance_matrix[None].to(mask.device) + (~mask[:, None]) * self.num_frames
         ).min(-1)[0]
         min_distance = min_distance / min_distance.max(-1, keepdim=True)[0].clamp(min=1)
         ramp = min_distance * (scale - self.scale_min) + self.scale_min
-        ramp = append_dims(ramp.reshape(-1), x.ndim)
-        ruled = self.scale_rule(ramp, c2w, K, mask.flatten(0, 1))
-        return self.scale_schedule(sigma, ruled)
+        ramp = append_dims(ramp.reshape(-1), ndim)
+        val = self.scale_rule(ramp, c2w, K, mask.flatten(0, 1))
+        self._rule_cache = ((scale, c2w, K, input_frame_mask), val)
+        return val
+
+    def frame_scale(self, x, sigma, scale, c2w=None, K=None, input_frame_mask=None, **_):
+        return self.scale_schedule(sigma, self._ruled_scale(scale, c2w, K, input_frame_mask, x.ndim))
 
     def __call__(self, x: torch.Tensor, sigma, scale, c2w: torch.Tensor, K: torch.Tensor,
                  input_frame_mask: torch.Tensor) -> torch.Tensor:
@@ -339,11 +366,14 @@ class EulerEDMSampler(object):
         self.s_tmax = s_tmax
         self.s_noise = s_noise
         self.noise_fn = torch.randn_like  # injectable: fn(x) -> N(0,1) tensor like x
+        self._step_graphs = _stepgraph.StepGraphCache()
 
     def prepare_sampling_loop(self, x: torch.Tensor, cond: dict, uc: dict, num_steps: int | None = None):
         num_steps = num_steps or self.num_steps
         assert num_steps is not None, "num_steps must be specified"
         _need_gpu(x)
+        if hasattr(self.guider, "reset_rule_cache"):
+            self.guider.reset_rule_cache()
         sigmas = self.discretization(num_steps, device=self.device)
         # x *= sqrt(1 + sigma_0^2), in place on the caller's tensor like the reference (l.331)
         s0 = torch.sqrt(1.0 + sigmas[0] ** 2.0).to(device=x.device, dtype=torch.float32)
@@ -366,18 +396,15 @@ class EulerEDMSampler(object):
             sigma_generator = tqdm(sigma_generator, total=num_sigmas - 1, desc="Sampling", leave=False)
         return sigma_generator
 
-    def sampler_step(self, sigma: torch.Tensor, next_sigma: torch.Tensor, denoiser, x: torch.Tensor,
-                     scale, cond: dict, uc: dict, gamma: float = 0.0, **guider_kwargs) -> torch.Tensor:
-        _need_gpu(x)
-        x = _f32c(x)
-        sigma = _f32c(sigma)
+    def _step_math(self, sigma, next_sigma, x, eps, denoiser, scale, cond, uc, gamma, guider_kwargs):
+        """Reference sampling.py:357-368 on f32 contiguous device tensors; sync-free once the guider's rule is cached,
+        which is what makes it capturable as one hipGraph (`_stepgraph.StepGraph`)."""
         sigma_hat = sigma * (gamma + 1.0) + 1e-6
-        eps = self.noise_fn(x)
         noise_scale = (sigma_hat**2 - sigma**2) ** 0.5 * self.s_noise
         x_noised = torch.empty_like(x)
-        ops.add_noise(x, _f32c(eps), _f32c(noise_scale), x_noised)
+        ops.add_noise(x, eps, _f32c(noise_scale), x_noised)
         denoised2 = denoiser(*self.guider.prepare_inputs(x_noised, sigma_hat, cond, uc))
-        dt = _f32c(next_sigma) - sigma_hat
+        dt = next_sigma - sigma_hat
         out = torch.empty_like(x)
         if hasattr(self.guider, "frame_scale"):
             # CFG combine + to_d + Euler update in one pass
@@ -388,6 +415,69 @@ class EulerEDMSampler(object):
             denoised = self.guider(denoised2, sigma_hat, scale, **guider_kwargs)
             ops.euler_step(x_noised, _f32c(denoised), sigma_hat, dt, out)
         return out
+
+    @staticmethod
+    def _flat_key(obj):
+        """Flatten dict / tensor / scalar arguments into a tuple compared by identity (tensors, callables) or value."""
+        if isinstance(obj, dict):
+            out = []
+            for k in sorted(obj):
+                out.append(k)
+                out.extend(EulerEDMSampler._flat_key(obj[k]))
+            return tuple(out)
+        if isinstance(obj, (list, tuple)):
+            out = []
+            for v in obj:
+                out.extend(EulerEDMSampler._flat_key(v))
+            return tuple(out)
+        return (obj,)
+
+    def sampler_step(self, sigma: torch.Tensor, next_sigma: torch.Tensor, denoiser, x: torch.Tensor,
+                     scale, cond: dict, uc: dict, gamma: float = 0.0, **guider_kwargs) -> torch.Tensor:
+        """One Euler-EDM step (reference sampling.py:347-368).  From the second step of a trajectory on, the whole
+        step is replayed from one hipGraph (see `_stepgraph`); the first step runs eagerly and warms every cache.
+        Stays a callable unit for `GradioTrackedSampler` (reference eval.py:1037-1089)."""
+        _need_gpu(x)
+        x = _f32c(x)
+        sigma = _f32c(sigma)
+        next_sigma = _f32c(next_sigma)
+        eps = _f32c(self.noise_fn(x))  # drawn eagerly: the generator advances per step exactly as in the reference
+        gamma = float(gamma)
+        cache = self._step_graphs
+        use_graph = (x.is_cuda and not cache.disabled and _stepgraph.enabled()
+                     and not torch.cuda.is_current_stream_capturing())
+        if not use_graph:
+            return self._step_math(sigma, next_sigma, x, eps, denoiser, scale, cond, uc, gamma, guider_kwargs)
+        key = (tuple(x.shape), gamma, float(self.s_noise), self.guider, denoiser) + self._flat_key(
+            (scale, cond, uc, guider_kwargs))
+        ent = cache.lookup(key)
+        if ent.state == 0:
+            # warm-up = the real first step, launched eagerly (also without the network-only graph: it would be
+            # captured for this one call only)
+            with _native.eager_network():
+                out = self._step_math(sigma, next_sigma, x, eps, denoiser, scale, cond, uc, gamma, guider_kwargs)
+            ent.state = 1
+            return out
+        if ent.graph is None:
+            try:
+                ent.graph = _stepgraph.StepGraph(
+                    lambda s, n, xx, ee: self._step_math(s, n, xx, ee, denoiser, scale, cond, uc, gamma, guider_kwargs),
+                    (sigma, next_sigma, x, eps))
+                cache.captures += 1
+            except Exception as e:  # a step that cannot be captured (foreign denoiser with host syncs, ...) runs eagerly
+                import warnings
+
+                cache.disabled = True
+                cache.reset()
+                try:
+                    torch.cuda.synchronize(x.device)
+                except Exception:
+                    pass
+                warnings.warn(f"seva: whole-step hipGraph capture failed ({type(e).__name__}: {e}); "
+                              "falling back to eager steps", RuntimeWarning)
+                return self._step_math(sigma, next_sigma, x, eps, denoiser, scale, cond, uc, gamma, guider_kwargs)
+        # the graph's output buffer is overwritten by the next replay: hand the caller its own copy (435 KB)
+        return ent.graph(sigma, next_sigma, x, eps).clone()
 
     def __call__(self, denoiser, x: torch.Tensor, scale, cond: dict, uc: dict | None = None,
                  num_steps: int | None = None, verbose: bool = True, **guider_kwargs) -> torch.Tensor:

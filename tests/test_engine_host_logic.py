@@ -265,3 +265,105 @@ def test_vae_encoder_orchestration_vs_restatement(monkeypatch):
     assert err < 3e-3
     with pytest.raises(ValueError):
         eng.encode(torch.zeros(1, 3, 20, 16), 0.18215)
+
+
+def _guider_oracle_scale(c2w, K, mask, scale=2.0, cfg_min=1.2):
+    """Independent restatement of the reference rule (sampling.py:160-187) for the cache tests."""
+    from oracle import sampling_ref as SR
+    T = c2w.shape[0]
+    d = torch.cat([torch.zeros(T, 1, 1, 1), torch.ones(T, 1, 1, 1)], 0)  # u = 0, c = 1  ->  result = scale per frame
+    return SR.guide(d, scale, 1, cfg_min, c2w, K, mask, T).reshape(T)
+
+
+def test_multiview_cfg_under_inference_mode_and_across_scenes(monkeypatch):
+    """reference do_sample creates c2w / K / mask under torch.inference_mode() (eval.py:1242,1286-1290):
+    the guider must not read `_version` there, and a second scene whose freshly allocated tensors reuse the first
+    scene's addresses must not be served the first scene's cached per-frame scale."""
+    from seva import sampling as S
+    from seva import synthetic as synth
+    monkeypatch.setattr(S, "ops", fake_ops)
+    monkeypatch.setattr(S, "_need_gpu", lambda *a: None)
+    T = 6
+    base = synth.orbit_c2w(T)
+    K = synth.default_K(T)
+    guider = S.MultiviewCFG(1.2)
+    d = torch.cat([torch.zeros(T, 4, 2, 2), torch.ones(T, 4, 2, 2)], 0)
+    sig = torch.ones(T)
+    with torch.inference_mode():
+        for trial in range(4):
+            # scene A: frame 0 is the input, frame 3 sits on the input pose; scene B: frame 2 is the input
+            c2w = base.clone()
+            mask = torch.zeros(T, dtype=torch.bool)
+            if trial % 2 == 0:
+                mask[0] = True
+                c2w[3] = c2w[0]
+            else:
+                mask[2] = True
+                c2w[5] = c2w[2]
+            Kc = K.clone()
+            for _ in range(3):  # several steps of one trajectory hit the cache
+                got = guider(d, sig, 2.0, c2w, Kc, mask)[:, 0, 0, 0]
+                want = _guider_oracle_scale(c2w.clone(), Kc.clone(), mask.clone())
+                assert torch.allclose(got, want), (trial, got, want)
+            ent = guider._rule_cache
+            assert ent is not None and ent[0][1] is c2w
+            del c2w, mask, Kc  # the allocator may hand the same storage to the next scene
+
+
+def test_sampler_resets_guider_cache_per_trajectory(monkeypatch):
+    from seva import sampling as S
+    monkeypatch.setattr(S, "ops", fake_ops)
+    monkeypatch.setattr(S, "_need_gpu", lambda *a: None)
+    guider = S.MultiviewCFG(1.2)
+    guider._rule_cache = (("stale",) * 4, torch.zeros(3))
+    sampler = S.EulerEDMSampler(S.DDPMDiscretization(), guider, num_steps=3, device="cpu")
+    sampler.prepare_sampling_loop(torch.zeros(3, 4, 2, 2), {}, {}, None)
+    assert guider._rule_cache is None
+
+
+def test_vae_loader_is_strict_and_maps_legacy_attention_names(tmp_path, monkeypatch):
+    """no silent random-init VAE, no silently dropped keys; the published SD-2.1 VAE file's
+    deprecated mid-block attention names (query/key/value/proj_attn, 1x1-conv shaped) must land in to_q/.../to_out.0."""
+    import warnings
+
+    import safetensors.torch
+    from seva.modules import autoencoder as A
+    monkeypatch.delenv("SEVA_VAE_PATH", raising=False)
+    monkeypatch.delenv("SEVA_VAE_RANDOM_INIT", raising=False)
+    with pytest.raises(RuntimeError, match="no VAE weights"):
+        A.AutoEncoder(chunk_size=1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ae = A.AutoEncoder(chunk_size=1, random_init=True)
+    assert ae.random_init and any("RANDOM-INIT" in str(x.message) for x in w)
+    # a checkpoint in the legacy naming, attention projections stored as 1x1 convs
+    g = torch.Generator().manual_seed(0)
+    sd = {k: torch.randn(v.shape, generator=g) for k, v in ae.module.state_dict().items()}
+    legacy = {}
+    inv = {v: k for k, v in A._LEGACY_ATTN.items()}
+    for k, v in sd.items():
+        m = re.match(r"^((?:encoder|decoder)\.mid_block\.attentions\.0)\.(to_q|to_k|to_v|to_out\.0)\.(weight|bias)$", k)
+        if m:
+            k2 = f"{m.group(1)}.{inv[m.group(2)]}.{m.group(3)}"
+            legacy[k2] = v[:, :, None, None].clone() if m.group(3) == "weight" else v
+        else:
+            legacy[k] = v
+    assert any(".query." in k for k in legacy)
+    path = str(tmp_path / "vae.safetensors")
+    safetensors.torch.save_file(legacy, path)
+    monkeypatch.setenv("SEVA_VAE_PATH", path)
+    ae2 = A.AutoEncoder(chunk_size=1)
+    assert not ae2.random_init
+    for k, v in ae2.module.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # one key missing -> loud failure
+    broken = dict(legacy)
+    broken.pop("decoder.mid_block.attentions.0.query.weight")
+    safetensors.torch.save_file(broken, path)
+    with pytest.raises(RuntimeError, match="missing"):
+        A.AutoEncoder(chunk_size=1)
+    extra = dict(legacy)
+    extra["decoder.something_else.weight"] = torch.zeros(3)
+    safetensors.torch.save_file(extra, path)
+    with pytest.raises(RuntimeError, match="unexpected"):
+        A.AutoEncoder(chunk_size=1)

@@ -287,7 +287,7 @@ def _vae(dev, block_out, seed=3):
     from oracle import vae_ref as V
     from seva import synthetic as synth
     from seva.modules.autoencoder import AutoEncoder, VaeWeights
-    ae = AutoEncoder(chunk_size=1)
+    ae = AutoEncoder(chunk_size=1, random_init=True)
     if tuple(block_out) != tuple(ae.module.block_out):
         ae.module = VaeWeights(block_out=block_out)
     sd = synth.synth_state_dict({**V.decoder_shapes(block_out=block_out), **V.encoder_shapes(block_out=block_out)}, seed)
@@ -423,3 +423,95 @@ def test_vae_encode_576_frame_and_chunking(dev):
     assert torch.equal(z[:1], z0)
     img = ae.decode(z, 1)
     assert img.shape == (2, 3, 576, 576) and torch.isfinite(img).all()
+
+
+# ------------------------------------------------------------------ whole-step hipGraph (seva/_stepgraph.py)
+def _loop(net, dev, T, hw, steps, eps, guider=None, inference=False):
+    from seva import sampling as S
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+    sc = synth.synth_scene(T, (hw, hw), (0,), seed=23)
+    disc = S.DDPMDiscretization()
+    den = S.DiscreteDenoiser(disc, num_idx=1000, device=dev)
+    sampler = S.EulerEDMSampler(disc, guider or S.MultiviewCFG(1.2), num_steps=steps, verbose=False, device=dev,
+                                s_churn=0.0)
+    it = iter(eps)
+    sampler.noise_fn = lambda x: next(it).to(x.device)
+    wrap = SGMWrapper(net)
+
+    def run():
+        cond = {k: v.to(dev) for k, v in sc["cond"].items()}
+        uc = {k: v.to(dev) for k, v in sc["uc"].items()}
+        return sampler(lambda x, s, c: den(wrap, x, s, c, num_frames=T), sc["noise"].to(dev), scale=2.0,
+                       cond=cond, uc=uc, verbose=False, c2w=sc["c2w"].to(dev), K=sc["K"].to(dev),
+                       input_frame_mask=sc["input_frame_mask"].to(dev))
+
+    if inference:
+        with torch.inference_mode():
+            return run().clone(), sampler
+    return run(), sampler
+
+
+@pytest.mark.parametrize("guider_kind", [0, 1, 2])
+def test_whole_step_graph_is_bit_identical_to_eager(dev, tiny, guider_kind, monkeypatch):
+    """6-step loop: step 0 eager (warm-up), step 1 captures the WHOLE sampler step into one hipGraph, steps 2-5 replay it;
+    the result must equal the all-eager loop bit for bit (same recorded eps on both sides)."""
+    from seva import sampling as S
+    net, _ = tiny
+    T, hw, steps = 4, 16, 6
+    g = torch.Generator().manual_seed(5)
+    eps = [torch.randn(T, 4, hw, hw, generator=g) for _ in range(steps)]
+    mk = lambda: [S.VanillaCFG(), S.MultiviewCFG(1.2), S.MultiviewTemporalCFG(T, 1.2)][guider_kind]  # noqa: E731
+    if guider_kind == 0:
+        pytest.skip("VanillaCFG takes no camera kwargs (reference eval.py passes them only to guiders 1/2)")
+    monkeypatch.setenv("SEVA_STEPGRAPH", "0")
+    monkeypatch.setenv("SEVA_HIPGRAPH", "0")
+    ref, s0 = _loop(net, dev, T, hw, steps, eps, mk())
+    assert s0._step_graphs.captures == 0
+    monkeypatch.setenv("SEVA_STEPGRAPH", "1")
+    monkeypatch.setenv("SEVA_HIPGRAPH", "1")
+    got, s1 = _loop(net, dev, T, hw, steps, eps, mk())
+    assert s1._step_graphs.captures == 1 and s1._step_graphs.graph.replays == steps - 1
+    assert torch.equal(got, ref)
+    # under torch.inference_mode() (how the reference's do_sample calls the sampler, eval.py:1242)
+    got_i, s2 = _loop(net, dev, T, hw, steps, eps, mk(), inference=True)
+    assert s2._step_graphs.captures == 1
+    assert torch.equal(got_i, ref)
+
+
+def test_to_d_and_euler_step_kernels(dev):
+    """`seva_to_d_f32` / `seva_euler_step_f32` (the guider-without-frame_scale branch, reference sampling.py:24-25,366-368)."""
+    from seva import ops
+    from seva import sampling as S
+    g = torch.Generator().manual_seed(3)
+    n, shape = 5, (5, 4, 9, 7)
+    x, den = torch.randn(shape, generator=g).to(dev), torch.randn(shape, generator=g).to(dev)
+    sigma = (torch.rand(n, generator=g) * 10 + 0.1).to(dev)
+    dt = (torch.randn(n, generator=g)).to(dev)
+    d = S.to_d(x, sigma, den)
+    ref_d = (x - den) / sigma[:, None, None, None]
+    assert torch.allclose(d, ref_d, rtol=2e-6, atol=1e-6)
+    out = torch.empty_like(x)
+    ops.euler_step(x, den, sigma, dt, out)
+    ref = x + dt[:, None, None, None] * ref_d
+    assert torch.allclose(out, ref, rtol=2e-6, atol=2e-6)
+
+    class PlainGuider:  # no frame_scale attribute: sampler_step takes the guider() + euler_step branch
+        def prepare_inputs(self, x, s, c, uc):
+            return S.VanillaCFG().prepare_inputs(x, s, c, uc)
+
+        def __call__(self, x, sigma, scale):
+            u, c = x.chunk(2)
+            return u + scale * (c - u)
+
+    sampler = S.EulerEDMSampler(S.DDPMDiscretization(), PlainGuider(), num_steps=4, device=dev)
+    eps = torch.randn(shape, generator=g).to(dev)
+    sampler.noise_fn = lambda t: eps
+    fake_den = lambda xx, ss, cc: xx * 0.5  # noqa: E731
+    s_in = torch.ones(n, device=dev)
+    o = sampler.sampler_step(s_in * 3.0, s_in * 2.0, fake_den, x, 2.0, {}, {}, 0.0)
+    sg = torch.full((n, 1, 1, 1), 3.0, device=dev)
+    sh = sg * 1.0 + 1e-6  # fp32, as the sampler computes it
+    xn = x + eps * (sh ** 2 - sg ** 2) ** 0.5
+    dd = (xn - 0.5 * xn) / sh
+    assert torch.allclose(o, xn + (2.0 - sh) * dd, rtol=1e-5, atol=1e-5)
