@@ -35,6 +35,8 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 # reference-equivalent dense FLOP per denoising step (FlopCounterMode on the reference)
+N_INPUT_VIEWS = 1          # synthetic scene: frame 0 is the input view
+NUM_STEPS_PER_WINDOW = 50  # reference default (demo.py:292-306 num_steps)
 FLOP_PER_STEP = {(21, 72): 7.691e13, (8, 72): 2.634e13, (24, 72): 8.999e13, (4, 32): 2.217e12}
 
 
@@ -185,33 +187,44 @@ def main():
     roofline = None
     if not args.no_roofline:
         eng = net.engine()
-        was_graph, eng.use_graph = eng.use_graph, False  # events bracket individual launches: run eagerly
+        # events bracket individual launches: this one instrumented step runs eagerly (no step graph, no network graph)
+        was_graph, eng.use_graph = eng.use_graph, False
+        was_step, sampler._step_graphs.disabled = sampler._step_graphs.disabled, True
         ops.prof_enable(True)
         with torch.no_grad():
             step(min(Wm + K, num_sigmas - 2), x)
         prof = ops.prof_collect()
         ops.prof_enable(False)
-        eng.use_graph = was_graph
+        eng.use_graph, sampler._step_graphs.disabled = was_graph, was_step
         mm = {k: prof[k] for k in ("gemm", "conv", "attention")}
         dom = max(mm, key=lambda k: mm[k]["ms"])
         d = mm[dom]
         ach = d["work"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
-        # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/traffic_from_pmc.py), not from here
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tfile) and (T, hw) == (21, 72):
-            t = json.load(open(tfile)).get(dom)
-            traffic = t["bytes_per_launch"] if t else None  # HBM bytes per launch of the dominant class
+        # HBM traffic of the dominant kernel class: measured by separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/traffic_from_pmc.py writes profiles/rNN_traffic.json,
+        # stamped with the git revision and command it was taken on).  It cannot be collected from inside this process,
+        # so the line names its source; `alg_bytes` (same unit, per launch) is computed live next to it.
+        traffic, traffic_source = None, None
+        tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+        if tfiles and (T, hw) == (21, 72):
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfiles[-1])))
+            t = tj.get(dom)
+            traffic = t["bytes_per_launch"] if t else None
+            traffic_source = {"file": "profiles/" + tfiles[-1], "git": tj.get("git"), "command": tj.get("command")}
         roofline = {
-            "bound": "mfma", "kernel": {"gemm": "gemm_kernel<plain>", "conv": "gemm_kernel<conv3x3>",
+            "bound": "mfma", "kernel": {"gemm": "gemm_kernel<plain|GEGLU>", "conv": "gemm_kernel<conv3x3>",
                                         "attention": "attn_kernel"}[dom],
             "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+            "traffic_source": traffic_source,
+            "alg_bytes": d["bytes"] / max(d["launches"], 1),
+            "alg_flop": d["work"] / max(d["launches"], 1),
             "launches": d["launches"], "avg_launch_ms": d["ms"] / max(d["launches"], 1),
             "classes_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
             "classes_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)
                                for k, v in mm.items()},
+            "classes_alg_gbps": {k: (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)
+                                 for k, v in prof.items()},
         }
 
     vae = None
@@ -247,15 +260,19 @@ def main():
         flop = FLOP_PER_STEP.get((T, hw))
         value = world * K / elapsed
         out = {
-            "metric": "denoising steps/sec, 1.3B Seva @ 21x576x576 views",
+            # the headline name is reserved for the headline shape; other shapes are labelled as what they are
+            "metric": (f"denoising steps/sec, 1.3B Seva @ {T}x{hw * 8}x{hw * 8} views"
+                       + ("" if (T, hw) == (21, 72) else " (NOT the 21x576x576 headline shape)")),
             "value": value, "unit": "denoising steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "novel_views_per_sec": value * (T - 1) / 50.0,
-            "hipgraph": bool(net.engine().use_graph),
+            "novel_views_per_sec": value * (T - N_INPUT_VIEWS) / NUM_STEPS_PER_WINDOW,
+            "hipgraph": {"whole_step": sampler._step_graphs.captures > 0,
+                         "step_replays": getattr(sampler._step_graphs.graph, "replays", 0),
+                         "network_only": bool(net.engine().use_graph) and sampler._step_graphs.captures == 0},
             "config": {"workload": f"Seva 1.3B (1,263,968,004 params, random-init), one {T}-view window per GPU, "
                                    f"{hw * 8}x{hw * 8} px (latent {hw}x{hw}), CFG batch {2 * T}, Euler-EDM step, "
-                                   "MultiviewCFG(1.2) cfg 2.0; novel_views_per_sec assumes 50 steps/window",
+                                   "MultiviewCFG(1.2) cfg 2.0; novel_views_per_sec = value x (T - 1 input view) / 50 steps per window",
                        "views": T, "latent": hw, "windows": world,
                        "flop_per_step": flop,
                        "model_tflops": (flop * value / 1e12) if flop else None},

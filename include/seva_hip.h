@@ -230,6 +230,15 @@ int seva_cond_concat_f32(const float* plucker, const uint8_t* mask, float* c_con
                          int32_t views, int32_t h, int32_t w, seva_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Benchmark / debugging knobs.  The library reads its SEVA_* environment variables ONCE, when it is loaded (nothing
+ * on the launch path calls getenv); a host changes a knob at run time with seva_set_knob (tests, tools).  Names:
+ * gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat, attn_dbg, attn_no_tr, attn_two,
+ * gn_min_iter (environment: SEVA_ + upper case).  -1 = unset (default heuristics).  None is needed in production.
+ */
+int seva_set_knob(const char* name, int32_t value);
+int seva_get_knob(const char* name, int32_t* value);
+
+/* ------------------------------------------------------------------------------------------
  * hipGraph helpers: capture everything enqueued on `stream` between begin/end, replay later.
  */
 int seva_graph_begin(seva_stream_t stream);
@@ -243,8 +252,9 @@ int seva_graph_destroy(void* graph_exec);
  */
 #define SEVA_PROF_CLASSES 5
 int seva_prof_enable(int on);
-/* Synchronises; fills ms[SEVA_PROF_CLASSES], launches[...], work[...] (flop or bytes); resets. */
-int seva_prof_collect(double* ms, int64_t* launches, double* work);
+/* Synchronises; fills ms[SEVA_PROF_CLASSES], launches[...], work[...] (algorithmic flop for classes 0-2, bytes for
+ * 3-4) and bytes[...] (algorithmic HBM bytes: every operand read once, every result written once); resets. */
+int seva_prof_collect(double* ms, int64_t* launches, double* work, double* bytes);
 
 #ifdef __cplusplus
 }

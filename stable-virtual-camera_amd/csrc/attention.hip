@@ -675,14 +675,13 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   a.o_sb0 = d->o_sb0; a.o_sb1 = d->o_sb1; a.o_sl = d->o_sl;
   a.nb1 = d->nb1; a.heads = d->heads; a.lq = d->lq; a.lk = d->lk;
   a.scale_log2 = d->scale * 1.44269504088896340736f;
-  a.dbg = 0;
-  if (const char* e = getenv("SEVA_ATTN_DBG")) a.dbg = atoi(e);
+  a.dbg = g_seva_knobs.attn_dbg > 0 ? g_seva_knobs.attn_dbg : 0;
   const int64_t batch = (int64_t)d->nb0 * d->nb1;
-  const char* no_tr = getenv("SEVA_ATTN_NO_TR");  // debug knob: scalar LDS reads instead of tr_b16
-  const bool use_tr = !(no_tr && no_tr[0] == '1');
+  const bool use_tr = g_seva_knobs.attn_no_tr != 1;  // knob attn_no_tr = 1: scalar LDS reads instead of tr_b16 (debug)
   hipStream_t s = (hipStream_t)stream;
   const double flops = 4.0 * (double)batch * d->heads * (double)d->lq * (double)d->lk * 64.0;
-  SevaProfScope prof(2, flops, s);
+  const double alg_bytes = (double)batch * d->heads * 64.0 * 2.0 * (2.0 * (double)d->lq + 2.0 * (double)d->lk);  // q, out, k, v
+  SevaProfScope prof(2, flops, s, alg_bytes);
   const bool pre = d->q_prescaled != 0;
   SEVA_REQUIRE(!pre || use_tr, "attention: q_prescaled is not available on the SEVA_ATTN_NO_TR debug path");
   if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr, pre);
@@ -690,8 +689,7 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   // (27.5 vs 27.3 ms/step): hipcc issues both chains' Q*K groups up front, the wave-uniform rescale
   // branches split the tile into basic blocks it does not schedule across, and 38 + 32 register moves per
   // tile appear at 251 VGPRs.  Kept, bit-compatible and tested, as the base for a hand-scheduled version.
-  const char* two = getenv("SEVA_ATTN_TWO");
-  if (pre && use_tr && !a.dbg && d->lq >= 512 && two && two[0] == '1') {
+  if (pre && use_tr && !a.dbg && d->lq >= 512 && g_seva_knobs.attn_two == 1) {
     AttnArgs args = a;
     args.qblocks = (a.lq + 255) / 256;
     const int64_t nb = batch * a.heads * args.qblocks;

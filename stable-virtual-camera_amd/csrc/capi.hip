@@ -3,6 +3,8 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <vector>
@@ -13,7 +15,7 @@ thread_local char g_err[512] = "";
 
 struct ProfRecord {
   int cls;
-  double work;
+  double work, bytes;
   hipEvent_t e0, e1;
 };
 std::mutex g_prof_mu;
@@ -21,6 +23,32 @@ std::vector<ProfRecord> g_prof;
 bool g_prof_on = false;
 
 }  // namespace
+
+namespace {
+struct KnobEntry {
+  const char* name;  // seva_set_knob() name; environment variable = "SEVA_" + upper-case name
+  const char* env;
+  int SevaKnobs::*field;
+};
+const KnobEntry kKnobs[] = {
+    {"gemm_chunks", "SEVA_GEMM_CHUNKS", &SevaKnobs::gemm_chunks}, {"gemm_dbg", "SEVA_GEMM_DBG", &SevaKnobs::gemm_dbg},
+    {"gemm_stagger", "SEVA_GEMM_STAGGER", &SevaKnobs::gemm_stagger}, {"gemm_cfg", "SEVA_GEMM_CFG", &SevaKnobs::gemm_cfg},
+    {"gemm_bm", "SEVA_GEMM_BM", &SevaKnobs::gemm_bm}, {"gemm_bn", "SEVA_GEMM_BN", &SevaKnobs::gemm_bn},
+    {"gemm_astat", "SEVA_GEMM_ASTAT", &SevaKnobs::gemm_astat}, {"attn_dbg", "SEVA_ATTN_DBG", &SevaKnobs::attn_dbg},
+    {"attn_no_tr", "SEVA_ATTN_NO_TR", &SevaKnobs::attn_no_tr}, {"attn_two", "SEVA_ATTN_TWO", &SevaKnobs::attn_two},
+    {"gn_min_iter", "SEVA_GN_MIN_ITER", &SevaKnobs::gn_min_iter},
+};
+SevaKnobs knobs_from_env() {
+  SevaKnobs k;
+  for (const auto& e : kKnobs) {
+    const char* v = getenv(e.env);
+    k.*(e.field) = (v && v[0]) ? atoi(v) : -1;
+  }
+  return k;
+}
+}  // namespace
+
+SevaKnobs g_seva_knobs = knobs_from_env();  // once, at library load
 
 void seva_set_error(const char* fmt, ...) {
   va_list ap;
@@ -38,8 +66,8 @@ int seva_check_launch(const char* what) {
   return SEVA_OK;
 }
 
-SevaProfScope::SevaProfScope(int cls_, double work_, hipStream_t stream_)
-    : cls(cls_), work(work_), stream(stream_), e0(nullptr), e1(nullptr), on(g_prof_on) {
+SevaProfScope::SevaProfScope(int cls_, double work_, hipStream_t stream_, double bytes_)
+    : cls(cls_), work(work_), bytes(bytes_ < 0 ? work_ : bytes_), stream(stream_), e0(nullptr), e1(nullptr), on(g_prof_on) {
   if (!on) return;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     on = false;
@@ -52,14 +80,36 @@ SevaProfScope::~SevaProfScope() {
   if (!on) return;
   (void)hipEventRecord(e1, stream);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back({cls, work, e0, e1});
+  g_prof.push_back({cls, work, bytes, e0, e1});
 }
 
 extern "C" {
 
 const char* seva_last_error(void) { return g_err; }
-int seva_abi_version(void) { return 4; }
+int seva_abi_version(void) { return 5; }
 const char* seva_target_arch(void) { return "gfx950"; }
+
+int seva_set_knob(const char* name, int value) {
+  SEVA_REQUIRE(name != nullptr, "set_knob: null name");
+  for (const auto& e : kKnobs)
+    if (strcmp(e.name, name) == 0) {
+      g_seva_knobs.*(e.field) = value;
+      return SEVA_OK;
+    }
+  seva_set_error("set_knob: unknown knob '%s'", name);
+  return SEVA_ERR_ARG;
+}
+
+int seva_get_knob(const char* name, int* value) {
+  SEVA_REQUIRE(name != nullptr && value != nullptr, "get_knob: null argument");
+  for (const auto& e : kKnobs)
+    if (strcmp(e.name, name) == 0) {
+      *value = g_seva_knobs.*(e.field);
+      return SEVA_OK;
+    }
+  seva_set_error("get_knob: unknown knob '%s'", name);
+  return SEVA_ERR_ARG;
+}
 
 int seva_graph_begin(seva_stream_t stream) {
   hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
@@ -110,8 +160,8 @@ int seva_prof_enable(int on) {
   return SEVA_OK;
 }
 
-int seva_prof_collect(double* ms, int64_t* launches, double* work) {
-  SEVA_REQUIRE(ms && launches && work, "prof_collect: null out");
+int seva_prof_collect(double* ms, int64_t* launches, double* work, double* bytes) {
+  SEVA_REQUIRE(ms && launches && work && bytes, "prof_collect: null out");
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     seva_set_error("prof_collect: %s", hipGetErrorString(e));
@@ -122,6 +172,7 @@ int seva_prof_collect(double* ms, int64_t* launches, double* work) {
     ms[i] = 0.0;
     launches[i] = 0;
     work[i] = 0.0;
+    bytes[i] = 0.0;
   }
   for (auto& r : g_prof) {
     float t = 0.f;
@@ -129,6 +180,7 @@ int seva_prof_collect(double* ms, int64_t* launches, double* work) {
       ms[r.cls] += t;
       launches[r.cls] += 1;
       work[r.cls] += r.work;
+      bytes[r.cls] += r.bytes;
     }
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);

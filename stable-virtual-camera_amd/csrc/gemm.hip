@@ -18,6 +18,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 namespace {
 
 constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
@@ -587,14 +589,19 @@ template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false>
 int launch_p(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * ((ASTAT ? 0 : BM) + BN) * 128 + (ASTAT ? 8192 : PAIRED ? 4096 : 0);  // + bias slots (ASYNC)
   constexpr bool DBG_BUILD = !ASTAT;  // the ablation instantiation only exists for the staged-A kernels
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the dynamic-LDS attribute is per device: one bit per device ordinal and instantiation (a second GPU in the
+  // same process would otherwise launch 72-80 KB kernels without it)
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t dev_bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (DBG_BUILD)
       (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_devs.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   GemmArgs args = a;
   args.tiles_m = (int)((a.M + BM - 1) / BM);
@@ -623,18 +630,13 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
     for (int c = base; c <= 2 * base && c <= args.tiles_n; ++c)  // nearest even split above `base`
       if (args.tiles_n % c == 0) { chunks = c; break; }
   }
-  // SEVA_GEMM_CHUNKS=n (benchmark knob) overrides the heuristic
-  if (const char* e = getenv("SEVA_GEMM_CHUNKS")) {
-    const int want = atoi(e);
-    if (want > 0) chunks = want;
-  }
+  // knob gemm_chunks (SEVA_GEMM_CHUNKS=n, benchmarking) overrides the heuristic
+  if (g_seva_knobs.gemm_chunks > 0) chunks = g_seva_knobs.gemm_chunks;
   if (chunks < 1) chunks = 1;
   if (chunks > args.tiles_n) chunks = args.tiles_n;
   args.n_chunks = chunks;
-  args.dbg = 0;
-  if (const char* e = getenv("SEVA_GEMM_DBG")) args.dbg = atoi(e);
-  args.stagger = 0;
-  if (const char* e = getenv("SEVA_GEMM_STAGGER")) args.stagger = atoi(e);
+  args.dbg = g_seva_knobs.gemm_dbg > 0 ? g_seva_knobs.gemm_dbg : 0;
+  args.stagger = g_seva_knobs.gemm_stagger > 0 ? g_seva_knobs.gemm_stagger : 0;
   const int64_t nb = (int64_t)args.tiles_m * chunks;
   if (nb <= 0 || nb > 0x7fffffff) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);
@@ -652,10 +654,9 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int MODE, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
-  // SEVA_GEMM_ASTAT=0 disables the A-in-registers variant (benchmark knob)
-  const char* const astat_env = getenv("SEVA_GEMM_ASTAT");
-  const bool astat_on = !(astat_env && astat_env[0] == '0');
-  const bool dbg_run = getenv("SEVA_GEMM_DBG") || getenv("SEVA_GEMM_STAGGER");
+  // knob gemm_astat = 0 (SEVA_GEMM_ASTAT=0) disables the A-in-registers variant (benchmarking)
+  const bool astat_on = g_seva_knobs.gemm_astat != 0;
+  const bool dbg_run = g_seva_knobs.gemm_dbg >= 0 || g_seva_knobs.gemm_stagger >= 0;
   if constexpr (EPI == 1) {
     if constexpr (BM == 128) {
       if (astat_on && !dbg_run && a.K <= 320 && a.out_f16 && !a.out_f32) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
@@ -731,31 +732,37 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
-  SevaProfScope prof(d->mode == 1 ? 1 : 0, flops, s);
+  // algorithmic HBM bytes: A (conv: the NHWC image) and W read once, residual read once, each output written once
+  const double a_elems = d->mode == 1 ? (double)d->n * d->ih * d->iw * d->cin : (double)d->M * (double)d->K;
+  const double n_out = d->epilogue == 1 ? (double)d->N / 2 : (double)d->N;
+  const double alg_bytes = 2.0 * a_elems + 2.0 * (double)d->N * (double)d->K + (d->bias ? 4.0 * (double)d->N : 0.0) +
+                           (double)d->M * n_out * ((d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) + (d->out_f16 ? 2.0 : 0.0));
+  SevaProfScope prof(d->mode == 1 ? 1 : 0, flops, s, alg_bytes);
   if (d->epilogue == 1) {
     SEVA_REQUIRE(d->N % 64 == 0, "geglu: N=%lld not a multiple of 64", (long long)d->N);
     SEVA_REQUIRE(d->mode == 0, "geglu: plain mode only");
     SEVA_REQUIRE(!d->out_f16 || d->ldo16 % 8 == 0, "geglu: f16 row pitch must be a multiple of 8");
   }
   const bool narrow = d->N <= 32;
-  // kernel choice: SEVA_GEMM_CFG = 0 (128x128 two-stage), 1/2/3 (ring variants), 4 (256x256 phased)
-  // overrides the shape heuristic (benchmarking knob)
-  int cfg = -1;
-  if (const char* e = getenv("SEVA_GEMM_CFG")) cfg = atoi(e);
-  if (cfg < 0) cfg = 0;
+#ifdef SEVA_EXPERIMENTAL
+  // experimental library only (make exp -> build_ab/libseva_hip_exp.so, loaded through SEVA_HIP_LIB for A/B runs): knob
+  // gemm_cfg = 1/2/3 (ring variants, gemm_ring.hip), 4 (256x256 phased, gemm_phase.hip).  None of them wins on any shape of
+  // this network, so the production library does not carry them.
+  const int cfg = g_seva_knobs.gemm_cfg;
   if (cfg == 4 && !narrow) return seva_gemm_phase_launch(a, d->mode, d->epilogue, s);
   if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
+#endif
   // Small problems (the ds8 level: 27 x 8 tiles of 128 rows on 512 workgroup slots) get 64-row tiles: twice the
   // workgroups, both slots of a CU busy.  SEVA_GEMM_BM=64|128 forces the height (benchmark knob).
   bool half_m = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
-  if (const char* e = getenv("SEVA_GEMM_BM")) half_m = atoi(e) == 64;
+  if (g_seva_knobs.gemm_bm > 0) half_m = g_seva_knobs.gemm_bm == 64;
   if (d->epilogue == 1) return half_m ? launch<64, 128, 0, 1>(a, s) : launch<128, 128, 0, 1>(a, s);
   // 128x160 tiles: every channel count of the network (320 .. 10240) is a multiple of 160, so no MFMA
   // column is idle (N = 320: 2 tiles instead of 3 with the last half empty), and a tile needs 10 %
   // fewer LDS-DMA bytes and fragment reads per FLOP than 128x128.  (128x64 tiles, tried earlier, were
   // 5-25 % slower: profiles/r01_kbench_bn64.log.)  SEVA_GEMM_BN=128|160 forces the width (benchmark knob).
   bool wide = d->N % 160 == 0;
-  if (const char* e = getenv("SEVA_GEMM_BN")) wide = atoi(e) == 160;
+  if (g_seva_knobs.gemm_bn > 0) wide = g_seva_knobs.gemm_bn == 160;
   if (d->mode == 0) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
     if (half_m) return wide ? launch<64, 160, 0, 0>(a, s) : launch<64, 128, 0, 0>(a, s);

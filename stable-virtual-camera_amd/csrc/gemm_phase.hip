@@ -391,7 +391,7 @@ int launch_phase(const GemmArgs& a, hipStream_t s) {
   }
   GemmArgs args = a;
   args.dbg = 0;
-  if (const char* e = getenv("SEVA_GEMM_DBG")) args.dbg = atoi(e);
+  if (g_seva_knobs.gemm_dbg > 0) args.dbg = g_seva_knobs.gemm_dbg;
   args.tiles_m = (int)((a.M + PB_BM - 1) / PB_BM);
   args.tiles_n = (int)((a.N + PB_BN - 1) / PB_BN);
   int chunks = (512 + args.tiles_m - 1) / args.tiles_m;  // one workgroup per CU: aim at >= 2 rounds

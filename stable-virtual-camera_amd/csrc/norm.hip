@@ -394,7 +394,7 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   // at the headline shapes (tools/kbench.py norm, SEVA_GN_MIN_ITER): 24 is best at every level (ds1 190, ds2 117,
   // ds4 68 us; 96 left ds2 / ds4 at 158 / 97 us with 1-3 workgroups per CU)
   int min_iter = d->dense ? 24 : 4;
-  if (const char* e = getenv("SEVA_GN_MIN_ITER")) min_iter = atoi(e) > 0 ? atoi(e) : min_iter;
+  if (g_seva_knobs.gn_min_iter > 0) min_iter = g_seva_knobs.gn_min_iter;
   const int nslab_apply = clampi(8192 / (d->n * zchunks), 1, clampi(d->hw / (min_iter * plc_apply), 1, 1024));
   hipStream_t s = (hipStream_t)stream;
   const double bytes = (double)d->n * d->hw * C * (4.0 + 4.0 + 2.0);

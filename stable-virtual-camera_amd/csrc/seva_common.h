@@ -29,14 +29,24 @@ int seva_check_launch(const char* what);
     }                                    \
   } while (0)
 
+// Benchmark / debugging knobs (capi.hip).  Read ONCE from the SEVA_* environment when the library is loaded (no
+// getenv on the launch path); tests and tools change them at run time through seva_set_knob().  -1 = unset.
+struct SevaKnobs {
+  int gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat;
+  int attn_dbg, attn_no_tr, attn_two;
+  int gn_min_iter;
+};
+extern SevaKnobs g_seva_knobs;
+
 // profiling (capi.hip) -- brackets a launch with events when enabled
 struct SevaProfScope {
   int cls;
-  double work;
+  double work;   // algorithmic FLOP (classes 0-2) or bytes (classes 3-4)
+  double bytes;  // algorithmic HBM bytes: every operand read once, every result written once
   hipStream_t stream;
   hipEvent_t e0, e1;
   bool on;
-  SevaProfScope(int cls, double work, hipStream_t stream);
+  SevaProfScope(int cls, double work, hipStream_t stream, double bytes = -1.0);  // bytes < 0: same as work
   ~SevaProfScope();
 };
 

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
 
@@ -88,12 +88,14 @@ SYMBOLS = {
     "seva_scale_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
     "seva_plucker_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "seva_cond_concat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "seva_set_knob": (c_int, [c_char_p, c_int32]),
+    "seva_get_knob": (c_int, [c_char_p, POINTER(c_int32)]),
     "seva_graph_begin": (c_int, [c_void_p]),
     "seva_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "seva_graph_launch": (c_int, [c_void_p, c_void_p]),
     "seva_graph_destroy": (c_int, [c_void_p]),
     "seva_prof_enable": (c_int, [c_int]),
-    "seva_prof_collect": (c_int, [POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
+    "seva_prof_collect": (c_int, [POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
 }
 
 _lib = None

@@ -333,6 +333,17 @@ def cond_concat(plucker_maps: torch.Tensor, mask_u8: torch.Tensor, c_concat: tor
           "seva_cond_concat_f32")
 
 
+# --- benchmark / debugging knobs (read from SEVA_* once at library load; see include/seva_hip.h) ---------
+def set_knob(name: str, value: int) -> None:
+    check(_lib().seva_set_knob(name.encode(), int(value)), "seva_set_knob")
+
+
+def get_knob(name: str) -> int:
+    v = C.c_int32()
+    check(_lib().seva_get_knob(name.encode(), C.byref(v)), "seva_get_knob")
+    return v.value
+
+
 # --- profiling / graphs ---------------------------------------------------------------------
 def prof_enable(on: bool) -> None:
     check(_lib().seva_prof_enable(1 if on else 0))
@@ -342,8 +353,9 @@ def prof_collect() -> dict:
     ms = (C.c_double * nv.PROF_CLASSES)()
     n = (C.c_int64 * nv.PROF_CLASSES)()
     work = (C.c_double * nv.PROF_CLASSES)()
-    check(_lib().seva_prof_collect(ms, n, work), "seva_prof_collect")
-    return {name: {"ms": ms[i], "launches": n[i], "work": work[i]}
+    nbytes = (C.c_double * nv.PROF_CLASSES)()
+    check(_lib().seva_prof_collect(ms, n, work, nbytes), "seva_prof_collect")
+    return {name: {"ms": ms[i], "launches": n[i], "work": work[i], "bytes": nbytes[i]}
             for i, name in enumerate(nv.PROF_NAMES)}
 
 

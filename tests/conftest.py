@@ -40,3 +40,21 @@ def golden():
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+KNOB_NAMES = ("gemm_chunks", "gemm_dbg", "gemm_stagger", "gemm_cfg", "gemm_bm", "gemm_bn", "gemm_astat",
+              "attn_dbg", "attn_no_tr", "attn_two", "gn_min_iter")
+
+
+@pytest.fixture
+def knobs():
+    """Set libseva_hip.so benchmark knobs for one test (seva_set_knob); every knob is back to 'unset' afterwards."""
+    from seva import ops
+
+    def set_(**kw):
+        for k, v in kw.items():
+            ops.set_knob(k, int(v))
+
+    yield set_
+    for k in KNOB_NAMES:
+        ops.set_knob(k, -1)

@@ -64,10 +64,10 @@ def test_gemm_exact_integers(dev, M, N, K):
 
 @pytest.mark.parametrize("bn", ["128", "160"])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (777, 132, 192), (257, 484, 64)])
-def test_gemm_tile_width_knob_exact(dev, M, N, K, bn, monkeypatch):
-    """Both tile widths (SEVA_GEMM_BN) on widths that leave ragged last tiles either way."""
+def test_gemm_tile_width_knob_exact(dev, M, N, K, bn, knobs):
+    """Both tile widths (knob gemm_bn) on widths that leave ragged last tiles either way."""
     from seva import ops
-    monkeypatch.setenv("SEVA_GEMM_BN", bn)
+    knobs(gemm_bn=bn)
     a = _ints((M, K), -4, 4, dev, 11)
     w = _ints((N, K), -3, 3, dev, 12)
     bias = _ints((N,), -5, 5, dev, 13)
@@ -80,14 +80,13 @@ def test_gemm_tile_width_knob_exact(dev, M, N, K, bn, monkeypatch):
 
 @pytest.mark.parametrize("astat", ["0", "1"])
 @pytest.mark.parametrize("M,N,K", [(300, 960, 320), (1000, 1920, 640), (515, 640, 192), (257, 2560, 320)])
-def test_gemm_f16_only_multi_tile_walk_exact(dev, M, N, K, astat, monkeypatch):
+def test_gemm_f16_only_multi_tile_walk_exact(dev, M, N, K, astat, knobs):
     """f16-only outputs take the ASYNC schedule (next-tile stages issued before the epilogue, counted vmcnt leaves the
-    stores in flight) and, for K <= 320, the A-in-registers variant.  One workgroup per M-tile (SEVA_GEMM_CHUNKS=1)
+    stores in flight) and, for K <= 320, the A-in-registers variant.  One workgroup per M-tile (knob gemm_chunks=1)
     makes it walk every N-tile, so the cross-tile bookkeeping is exercised; exact on integers, with bias, column
     scale and ragged M."""
     from seva import ops
-    monkeypatch.setenv("SEVA_GEMM_CHUNKS", "1")
-    monkeypatch.setenv("SEVA_GEMM_ASTAT", astat)
+    knobs(gemm_chunks=1, gemm_astat=astat)
     a = _ints((M, K), -4, 4, dev, 61)
     w = _ints((N, K), -3, 3, dev, 62)
     bias = _ints((N,), -5, 5, dev, 63)
@@ -102,11 +101,10 @@ def test_gemm_f16_only_multi_tile_walk_exact(dev, M, N, K, astat, monkeypatch):
 
 @pytest.mark.parametrize("astat", ["0", "1"])
 @pytest.mark.parametrize("M,C,K", [(300, 320, 320), (1000, 640, 640)])
-def test_geglu_multi_tile_walk(dev, M, C, K, astat, monkeypatch):
+def test_geglu_multi_tile_walk(dev, M, C, K, astat, knobs):
     from seva import ops
     from seva._engine import interleave_geglu
-    monkeypatch.setenv("SEVA_GEMM_CHUNKS", "1")
-    monkeypatch.setenv("SEVA_GEMM_ASTAT", astat)
+    knobs(gemm_chunks=1, gemm_astat=astat)
     a = _rand((M, K), dev, 71).half()
     w = (_rand((8 * C, K), dev, 72) * K ** -0.5).half()
     b = _rand((8 * C,), dev, 73)
@@ -120,25 +118,26 @@ def test_geglu_multi_tile_walk(dev, M, C, K, astat, monkeypatch):
 
 @pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 4, 64), (777, 960, 640), (4097, 132, 192)])
-def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg):
-    """The ring (cfg 1-3) and phased (cfg 4) GEMM kernels are kept bit-exact with the default one."""
+def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg, knobs):
+    """The ring (cfg 1-3) and phased (cfg 4) GEMM kernels live in the EXPERIMENTAL library only
+    (`make -C stable-virtual-camera_amd/csrc exp`, loaded with SEVA_HIP_LIB=build_ab/libseva_hip_exp.so); there they
+    stay bit-exact with the default kernel.  Skipped against the production library, which does not carry them."""
     from seva import ops
-    os.environ["SEVA_GEMM_CFG"] = cfg
-    try:
-        a, w = _ints((M, K), -4, 4, dev, 1), _ints((N, K), -3, 3, dev, 2)
-        bias, res = _ints((N,), -5, 5, dev, 3), _ints((M, N), -9, 9, dev, 4)
-        o32 = torch.full((M, N), float("nan"), device=dev)
-        ops.gemm(a.half(), w.half(), bias=bias, residual=res, out_f32=o32)
-        assert torch.equal(o32, a @ w.T + bias + res)
-        x = _ints((2, 64, 9, 7), -3, 3, dev, 5)
-        wc = _ints((96, 64, 3, 3), -2, 2, dev, 6)
-        from seva._engine import pack_conv3x3
-        out = torch.full((2, 63, 96), float("nan"), device=dev)
-        ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(wc), out_f32=out)
-        ref = F.conv2d(x, wc, None, padding=1)
-        assert torch.equal(out.view(2, 9, 7, 96).permute(0, 3, 1, 2), ref)
-    finally:
-        os.environ.pop("SEVA_GEMM_CFG", None)
+    if "exp" not in os.path.basename(os.environ.get("SEVA_HIP_LIB", "")):
+        pytest.skip("production libseva_hip.so carries no experimental GEMM kernels")
+    knobs(gemm_cfg=cfg)
+    a, w = _ints((M, K), -4, 4, dev, 1), _ints((N, K), -3, 3, dev, 2)
+    bias, res = _ints((N,), -5, 5, dev, 3), _ints((M, N), -9, 9, dev, 4)
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a.half(), w.half(), bias=bias, residual=res, out_f32=o32)
+    assert torch.equal(o32, a @ w.T + bias + res)
+    x = _ints((2, 64, 9, 7), -3, 3, dev, 5)
+    wc = _ints((96, 64, 3, 3), -2, 2, dev, 6)
+    from seva._engine import pack_conv3x3
+    out = torch.full((2, 63, 96), float("nan"), device=dev)
+    ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(wc), out_f32=out)
+    ref = F.conv2d(x, wc, None, padding=1)
+    assert torch.equal(out.view(2, 9, 7, 96).permute(0, 3, 1, 2), ref)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (2049, 1280, 1280)])
@@ -221,27 +220,24 @@ def _attn_ref(q, k, v, scale):
 @pytest.mark.parametrize("no_tr", ["0", "1"])
 @pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 200, 200), (2, 5, 128, 128), (1, 1, 1701, 1701),
                                        (2, 3, 70, 5), (4, 2, 21, 21), (1, 2, 33, 64)])
-def test_attention_fused_qkv(dev, B, H, Lq, Lk, no_tr):
+def test_attention_fused_qkv(dev, B, H, Lq, Lk, no_tr, knobs):
     """q,k,v as column slices of a [B, L, 3C] buffer (the layout the engine uses)."""
     from seva import ops
-    os.environ["SEVA_ATTN_NO_TR"] = no_tr
-    try:
-        C = 64 * H
-        L = max(Lq, Lk)
-        qkv = _rand((B, L, 3 * C), dev, 7).half()
-        out = torch.full((B, Lq, C), float("nan"), device=dev, dtype=torch.float16)
-        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-        ops.attention(q, k, v, out, nb0=B, nb1=1, heads=H, lq=Lq, lk=Lk,
-                      q_strides=(L * 3 * C, 0, 3 * C), k_strides=(L * 3 * C, 0, 3 * C),
-                      o_strides=(Lq * C, 0, C))
-        qh = q[:, :Lq].reshape(B, Lq, H, 64).transpose(1, 2)
-        kh = k[:, :Lk].reshape(B, Lk, H, 64).transpose(1, 2)
-        vh = v[:, :Lk].reshape(B, Lk, H, 64).transpose(1, 2)
-        ref = _attn_ref(qh, kh, vh, 0.125).transpose(1, 2).reshape(B, Lq, C)
-        err = rel_l2(out, ref)
-        assert err < 2e-3, f"rel_l2 {err}"
-    finally:
-        os.environ.pop("SEVA_ATTN_NO_TR", None)
+    knobs(attn_no_tr=no_tr)
+    C = 64 * H
+    L = max(Lq, Lk)
+    qkv = _rand((B, L, 3 * C), dev, 7).half()
+    out = torch.full((B, Lq, C), float("nan"), device=dev, dtype=torch.float16)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ops.attention(q, k, v, out, nb0=B, nb1=1, heads=H, lq=Lq, lk=Lk,
+                  q_strides=(L * 3 * C, 0, 3 * C), k_strides=(L * 3 * C, 0, 3 * C),
+                  o_strides=(Lq * C, 0, C))
+    qh = q[:, :Lq].reshape(B, Lq, H, 64).transpose(1, 2)
+    kh = k[:, :Lk].reshape(B, Lk, H, 64).transpose(1, 2)
+    vh = v[:, :Lk].reshape(B, Lk, H, 64).transpose(1, 2)
+    ref = _attn_ref(qh, kh, vh, 0.125).transpose(1, 2).reshape(B, Lq, C)
+    err = rel_l2(out, ref)
+    assert err < 2e-3, f"rel_l2 {err}"
 
 
 QK_C = 0.125 * 1.4426950408889634
@@ -251,13 +247,13 @@ QK_C = 0.125 * 1.4426950408889634
                                        (1, 2, 33, 64), (2, 1, 500, 777), (2, 2, 1024, 900), (1, 3, 777, 1300)])
 @pytest.mark.parametrize("spike", [False, True])
 @pytest.mark.parametrize("two", ["0", "1"])
-def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, monkeypatch):
+def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, knobs):
     """q already multiplied by scale*log2(e) (what the engine's QKV projection emits): the kernel starts
     its score accumulators at -m_run and exponentiates the MFMA output directly.  `spike` plants, late in
     the key sequence, keys that beat the running maximum by far more than the deferred-rescale threshold
     (rescale branch), and shifts all logits of the first tile far below zero (first-tile reference)."""
     from seva import ops
-    monkeypatch.setenv("SEVA_ATTN_TWO", two)  # "1": the opt-in two-chain kernel for Lq >= 512
+    knobs(attn_two=two)  # 1: the opt-in two-chain kernel for Lq >= 512
     C = 64 * H
     g = torch.Generator().manual_seed(31)
     q = torch.randn((B, Lq, H, 64), generator=g)

@@ -24,8 +24,7 @@ for case in range(ncases):
         mode = "s2"
     for k, vals in (("SEVA_GEMM_BN", [None, "128", "160"]), ("SEVA_GEMM_BM", [None, "64", "128"]), ("SEVA_GEMM_CHUNKS", [None, "1", "2"])):
         v = rng.choice(vals)
-        if v is None: os.environ.pop(k, None)
-        else: os.environ[k] = v
+        ops.set_knob(k[5:].lower(), -1 if v is None else int(v))  # knobs are read from the environment only at load
     x, w, b = ints((n, cin, ih, iw), -3, 3), ints((cout, cin, 3, 3), -2, 2), ints((cout,), -4, 4)
     xi = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
     if mode == "s2br":

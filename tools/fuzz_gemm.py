@@ -21,8 +21,7 @@ for case in range(ncases):
     for k, vals in (("SEVA_GEMM_CHUNKS", [None, "1", "2", "3", "5"]), ("SEVA_GEMM_BN", [None, "128", "160"]),
                     ("SEVA_GEMM_BM", [None, "64", "128"]), ("SEVA_GEMM_ASTAT", [None, "0"])):
         v = rng.choice(vals)
-        if v is None: os.environ.pop(k, None)
-        else: os.environ[k] = v
+        ops.set_knob(k[5:].lower(), -1 if v is None else int(v))  # knobs are read from the environment only at load
     a, w, bias = ints((M, K), -4, 4), ints((N, K), -3, 3), ints((N,), -5, 5)
     res = ints((M, N), -9, 9) if "res" in kind else None
     rpg = rng.choice([1, 5, 64])

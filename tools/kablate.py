@@ -24,7 +24,7 @@ for M, N, K, fl in SHAPES:
     res = torch.randn(M, N, device=dev) if fl == "o32res" else None
     line = f"{M}x{N}x{K} {fl:7s}"
     for bits, name in MODES:
-        os.environ["SEVA_GEMM_DBG"] = str(bits)
+        ops.set_knob("gemm_dbg", bits if bits else -1)
         us = timeit(lambda: ops.gemm(a, w, residual=res, out_f32=o32, out_f16=o16))
         line += f" | {name}: {us:6.1f}"
     print(line, flush=True)

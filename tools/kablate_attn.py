@@ -20,7 +20,7 @@ for B, H, L in [(2, 10, 27216), (42, 5, 5184)]:
     o = torch.empty(B * L, C, device=dev, dtype=torch.float16)
     line = f"B{B} H{H} L{L}"
     for bits, name in MODES:
-        os.environ["SEVA_ATTN_DBG"] = str(bits)
+        ops.set_knob("attn_dbg", bits if bits else -1)
         us = timeit(lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, nb0=B, nb1=1, heads=H, lq=L, lk=L,
                                           q_strides=(L * 3 * C, 0, 3 * C), k_strides=(L * 3 * C, 0, 3 * C), o_strides=(L * C, 0, C)))
         line += f" | {name}: {us:7.0f}us {4.0 * B * H * L * L * 64 / us / 1e6:5.0f}TF"

@@ -23,7 +23,7 @@ for M, N, K in SH:
     o = torch.empty(M, N, device=dev, dtype=torch.float16)
     line = f"{M}x{N}x{K} f16out |"
     for c in CFG:
-        os.environ["SEVA_GEMM_CFG"] = str(c)
+        ops.set_knob("gemm_cfg", c)  # needs SEVA_HIP_LIB=build_ab/libseva_hip_exp.so for c > 0
         us = timeit(lambda: ops.gemm(a, w, out_f16=o))
         line += f" cfg{c}: {us:8.1f}us {2.0*M*N*K/us/1e6:6.0f}TF |"
     print(line, flush=True)

@@ -25,7 +25,7 @@ for N, geglu in [(960, False), (2560, True)]:
     res = {c: [] for c in cfgs}
     for rnd in range(4):  # interleaved rounds: clock / thermal drift hits every config alike
         for bn, ast in cfgs:
-            os.environ["SEVA_GEMM_BN"] = bn; os.environ["SEVA_GEMM_ASTAT"] = ast
+            ops.set_knob("gemm_bn", int(bn)); ops.set_knob("gemm_astat", int(ast))
             res[(bn, ast)].append(timeit(lambda: ops.gemm(a, w, bias=b, out_f16=o, geglu=geglu, col_scale=0.18 if not geglu else 1.0, col_scale_n=320 if not geglu else 0)))
     line = f"{M}x{N}x{K} {'geglu' if geglu else 'qkv  '}"
     for c in cfgs:

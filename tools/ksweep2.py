@@ -26,8 +26,7 @@ for M, N, K, geglu in CASES:
     res = {c: [] for c in CH}
     for rnd in range(3):
         for c in CH:
-            if c: os.environ["SEVA_GEMM_CHUNKS"] = str(c)
-            else: os.environ.pop("SEVA_GEMM_CHUNKS", None)
+            ops.set_knob("gemm_chunks", c if c else -1)
             res[c].append(timeit(lambda: ops.gemm(a, w, bias=b, out_f16=o, geglu=geglu)))
     tn = (N + (127 if geglu or N % 160 else 159)) // (128 if geglu or N % 160 else 160)
     print(f"{M}x{N}x{K} {'geglu' if geglu else 'plain'} tn={tn} | " + " ".join(f"c{c}:{sorted(v)[1]:6.1f}" for c, v in res.items()), flush=True)

@@ -34,7 +34,7 @@ for M, N, K, kind in SH:
     tn = (N + 127) // 128
     line = f"{M}x{N}x{K} {kind:5s} tm={(M+127)//128} tn={tn} |"
     for c in CH:
-        os.environ["SEVA_GEMM_CHUNKS"] = str(c)
+        ops.set_knob("gemm_chunks", c)
         us = timeit(fn)
         line += f" c{c}:{us:7.1f}"
     print(line, flush=True)
