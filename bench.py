@@ -118,6 +118,59 @@ def cpu_baseline(sd):
     }
 
 
+def trajectory_mode(args, net, device, rank, world):
+    """BASELINE config 4: an N-view orbit, 1 input view, two-pass `interp` plan (1 + 10 windows of 21 views at N=168),
+    50 steps per window.  Reports BOTH definitions SURVEY §8e names: the shardable second-pass throughput and the
+    whole-trajectory wall time including the serial first pass, the anchor all-gather and the gather to rank 0."""
+    from seva import pipeline
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+
+    n, hw, T = args.trajectory, args.latent, args.views
+    c2ws, Ks = synth.orbit_c2w(n), synth.default_K(n)
+    g = torch.Generator().manual_seed(23)
+    lat = (torch.randn(1, 4, hw, hw, generator=g) * 0.18215 * 5.0).to(device)
+    tok = torch.randn(1024, generator=g)
+    tok = (tok / tok.norm()).to(device)
+    wrap = SGMWrapper(net)
+    plan = pipeline.plan_trajectory(c2ws, [0], T=T)
+    timers: dict = {}
+    with torch.no_grad():
+        # untimed warm-up: one short window fills the engine arena and every lazily packed weight on each rank
+        pipeline.run_window(plan.pass2[0], {f: lat[0] for f in range(n)}, wrap, c2ws, Ks, hw=(hw, hw), num_steps=2, cfg=2.0,
+                            cfg_min=1.2, guider=1, camera_scale=2.0, noise=torch.randn(T, 4, hw, hw), step_seed=1,
+                            clip_token=tok, device=device)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        res = pipeline.run_trajectory(wrap, lat, c2ws, Ks, [0], clip_token=tok, T=T, num_steps=args.traj_steps,
+                                      device=device, plan=plan, timers=timers)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    t = torch.tensor([timers["pass1"] - timers["start"], timers["exchange"] - timers["pass1"],
+                      timers["pass2"] - timers["exchange"], timers["gather"] - timers["pass2"],
+                      timers["gather"] - timers["start"]], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    p1, ex, p2, ga, total = (float(v) for v in t)
+    if rank == 0:
+        assert torch.isfinite(res["latents"]).all()
+        steps2 = len(plan.pass2) * args.traj_steps
+        print(json.dumps({
+            "metric": f"novel views/sec, 1.3B Seva, {n}-view orbit in {len(plan.pass1)}+{len(plan.pass2)} windows of {T} views "
+                      f"@ {hw * 8}x{hw * 8} (BASELINE config 4)",
+            "value": (n - 1) / total, "unit": "novel views/s (whole trajectory, first pass included)",
+            "n_gpus": world, "higher_is_better": True, "scaling": "strong", "dtype": "f16", "data": "synthetic",
+            "wall_s": total, "pass1_s": p1, "anchor_allgather_s": ex, "pass2_s": p2, "gather_s": ga,
+            "pass2_steps_per_sec": steps2 / p2, "pass2_windows": len(plan.pass2), "pass1_windows": len(plan.pass1),
+            "steps_per_window": args.traj_steps, "anchors": len(plan.anchor_ids),
+            "handoff": "anchor latents (no decode/encode round trip); VAE decode of the 167 frames not included",
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +178,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--views", type=int, default=21, help="frames per window (T)")
     ap.add_argument("--latent", type=int, default=72, help="latent side (576/8)")
+    ap.add_argument("--trajectory", type=int, default=0,
+                    help="BASELINE config 4 mode: generate an N-view orbit (1 input view) with the two-pass pipeline "
+                         "(seva/pipeline.py), windows sharded over the ranks; prints its own JSON line")
+    ap.add_argument("--traj-steps", type=int, default=50, help="sampler steps per window in --trajectory mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
@@ -149,6 +206,8 @@ def main():
     T, hw, K, Wm = args.views, args.latent, args.steps, args.warmup
     net, sd = build_model(device)
     net = net.to(device).eval()
+    if args.trajectory:
+        return trajectory_mode(args, net, device, rank, world)
     total_steps = K + Wm
     sampler, denoise, noise, cond, uc, gk = make_sampler(net, device, T, hw, max(total_steps, 2), 23 + rank)
 
@@ -161,6 +220,12 @@ def main():
                                     0.0, **gk)
 
     with torch.no_grad():
+        # set-up (like a compile step, outside warm-up and timing): the first call of a trajectory runs eagerly and fills
+        # every cache, the second captures the whole sampler step into one hipGraph; W warm-up and K timed steps replay it
+        scratch = x.clone()
+        for i in range(2):
+            scratch = step(i, scratch)
+        del scratch
         for i in range(Wm):
             x = step(i, x)
         if world > 1:

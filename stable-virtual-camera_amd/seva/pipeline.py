@@ -1,0 +1,283 @@
+"""Two-pass trajectory driver over the hot path (BASELINE config 4: 168-view orbit on 8 GPUs).
+
+Composes what the reference's `run_one_scene` does in its 2-pass branch (seva/eval.py:1631-1959) out of this
+package's parts, one process per GPU:
+
+    planner.two_pass_plan            anchors + pass-1 windows + pass-2 windows            (host, every rank, identical)
+    pass 1   windows that read only the input views are sharded round-robin over the ranks; a strategy whose windows
+             consume earlier windows' outputs (`gt-nearest`, eval.py:1720-1740) runs serially on rank 0
+    exchange ONE all-gather of the anchor latents (RCCL over xGMI; <= 20 x 4 x 72 x 72 fp32 = 1.66 MB per rank slot)
+    pass 2   windows read only {input views, anchors} (eval.py:1890-1906): independent units, `shard_windows`
+    gather   finished window latents to rank 0 (round by round), reassembled in target order, optionally VAE-decoded
+
+Hand-off between the passes: the reference carries the anchors across the pass boundary as decoded RGB and re-encodes
+them per window (eval.py:1820-1829, 1246).  Here the default hand-off is the anchor LATENT itself (`handoff="latent"`:
+no decode -> encode round trip, 1.66 MB instead of 40 MB on the wire); `handoff="rgb"` reproduces the reference's
+round trip through `AutoEncoder.decode` / `.encode` when an `ae` is given.
+
+Randomness under sharding (SURVEY §8e last bullet; reference eval.py:1294-1295, 1450): the initial noise of window i is
+the i-th `torch.randn((T,4,h,w))` draw of ONE CPU stream seeded once per scene -- every rank draws the whole sequence
+in plan order and keeps its own windows'.  The per-step device noise (`randn_like`, sampling.py:359) comes from a
+generator owned by the window (seed = scene seed, window index), so a window's result does not depend on which rank
+runs it or on what ran before it: a sharded run equals the sequential run bit for bit (tested on gloo, world size 2).
+
+The CLIP image conditioner is not part of this path: the caller supplies the 1024-d token
+(`clip_token`, or `clip_fn(window_source_ids) -> (1024,)` to vary it per window like eval.py:1248).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import conditioning, planner
+from . import sampling as S
+from .distributed import shard_windows
+
+DEPENDENT_FIRST_PASS = ("gt-nearest", "gt-ltr")  # windows consume earlier windows' outputs (eval.py:530-616)
+
+
+@dataclass
+class Window:
+    pass_id: int                  # 1 or 2
+    index: int                    # position inside its pass
+    global_index: int             # position in the scene-wide draw order of the initial noise
+    source_ids: list[int]         # trajectory frame ids of the conditioning frames (inputs, earlier outputs, anchors)
+    source_slots: list[int]
+    target_ids: list[int]         # trajectory frame ids this window generates
+    target_slots: list[int]
+    slot_frame: list[int] = field(default_factory=list)   # per slot: trajectory frame id (padding repeats a frame)
+    slot_is_input: list[bool] = field(default_factory=list)
+
+
+@dataclass
+class TrajectoryPlan:
+    T: int
+    input_ids: list[int]
+    anchor_ids: list[int]
+    pass1: list[Window]
+    pass2: list[Window]
+    pass1_serial: bool
+
+
+def _windows(pass_id, base, T, chunks, src_pool, tgt_pool, padding_mode="last"):
+    _, ins, in_slots, tes, te_slots = chunks
+    out = []
+    for i, (ci, cs, ti, ts) in enumerate(zip(ins, in_slots, tes, te_slots)):
+        cs2, ts2, in_map, te_map = planner.pad_indices(list(cs), list(ts), T=T, padding_mode=padding_mode)
+        slot_frame, slot_in = [], []
+        for s in range(T):
+            if in_map[s] != -1:
+                slot_frame.append(src_pool[ci[in_map[s]]])
+                slot_in.append(True)
+            else:
+                slot_frame.append(tgt_pool[ti[te_map[s]]])
+                slot_in.append(False)
+        out.append(Window(pass_id, i, base + i, [src_pool[j] for j in ci], list(cs), [tgt_pool[j] for j in ti], list(ts),
+                          slot_frame, slot_in))
+        # a padded slot that repeats an INPUT frame is conditioning too (reference: curr_input_sels after pad_indices)
+        out[-1].source_slots = [s for s in range(T) if slot_in[s]]
+    return out
+
+
+def plan_trajectory(c2ws: torch.Tensor, input_ids: Sequence[int], T: int = 21, chunk_strategy: str = "interp",
+                    first_pass_strategy: str = "gt", options: dict | None = None,
+                    task: str = "img2trajvid") -> TrajectoryPlan:
+    """Anchors + windows of both passes for one trajectory; frame ids index `c2ws` (inputs first, like the reference's
+    `input_indices` convention in run_one_scene)."""
+    n = c2ws.shape[0]
+    ins = [int(i) for i in input_ids]
+    opts = {"sampler_verbose": False, **(options or {}), "chunk_strategy": chunk_strategy}
+    vd = {"T": T, "options": opts}
+    n_prior = planner.infer_prior_stats(T, len(ins), n - len(ins), vd)
+    T1, T2 = vd["T"] if isinstance(vd["T"], (list, tuple)) else (T, T)
+    assert T1 == T2 == T, "different window lengths per pass are not driven by this pipeline"
+    anchors = [int(v) for v in planner.infer_prior_inds(c2ws, n_prior, ins, opts)]
+    p1 = planner.chunk_input_and_test(T, c2ws[ins], c2ws[anchors], [float(i) for i in ins], [float(a) for a in anchors],
+                                      opts, task=task, chunk_strategy=first_pass_strategy,
+                                      gt_input_inds=list(range(len(ins))))
+    serial = first_pass_strategy in DEPENDENT_FIRST_PASS
+    # pass-1 source pool: the inputs, then (dependent strategies) the anchors in the order they are generated
+    pool1 = list(ins)
+    if serial:
+        for ti in p1[3]:
+            pool1.extend(anchors[j] for j in ti)
+    w1 = _windows(1, 0, T, p1, pool1, anchors, opts.get("t_padding_mode", "last"))
+    order = np.argsort(ins + anchors).tolist()
+    pool2 = [(ins + anchors)[o] for o in order]
+    rest = [i for i in range(n) if i not in set(ins) and i not in set(anchors)]
+    p2 = planner.chunk_input_and_test(T, c2ws[pool2], c2ws[rest], [float(i) for i in pool2], [float(r) for r in rest],
+                                      opts, task=task, chunk_strategy=chunk_strategy,
+                                      gt_input_inds=[order.index(i) for i in range(len(ins))])
+    w2 = _windows(2, len(w1), T, p2, pool2, rest)
+    return TrajectoryPlan(T, ins, anchors, w1, w2, serial)
+
+
+def _rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _all_gather_padded(local: torch.Tensor, count: int, max_count: int, group=None) -> list[torch.Tensor]:
+    """All-gather of per-rank tensors with different leading sizes: each rank pads to `max_count` rows."""
+    rank, world = _rank_world(group)
+    if world == 1:
+        return [local[:count]]
+    buf = torch.zeros((max_count,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[:count] = local[:count]
+    out = torch.empty((world * max_count,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    return list(out.view(world, max_count, *local.shape[1:]).unbind(0))
+
+
+def run_window(win: Window, latents_of: dict, denoise_net: Callable, c2ws, Ks, *, hw, num_steps, cfg, cfg_min, guider,
+               camera_scale, noise: torch.Tensor, step_seed: int, clip_token: torch.Tensor, device,
+               sampler_hook: Callable | None = None) -> torch.Tensor:
+    """One window = the reference's get_value_dict + do_sample (eval.py:1152-1321) on this package's parts.
+    `latents_of[frame_id]` -> (4,h,w) latent of every conditioning frame.  Returns the (T,4,h,w) sample."""
+    T = len(win.slot_frame)
+    h, w = hw
+    frames = win.slot_frame
+    mask = torch.tensor(win.slot_is_input, dtype=torch.bool)
+    in_slots = [s for s in range(T) if win.slot_is_input[s]]
+    vd = conditioning.get_value_dict((h * 8, w * 8), in_slots, c2ws[frames][:, :3], Ks[frames].clone(), c2ws,
+                                     camera_scale, device=device)
+    lat = torch.stack([latents_of[frames[s]] for s in in_slots]).to(device)
+    cond, uc = conditioning.assemble_cond(lat, clip_token, mask, vd["plucker_coordinate"])
+    disc = S.DDPMDiscretization()
+    den = S.DiscreteDenoiser(disc, num_idx=1000, device=device)
+    g = [S.VanillaCFG(), S.MultiviewCFG(cfg_min), S.MultiviewTemporalCFG(T, cfg_min)][guider]
+    sampler = S.EulerEDMSampler(disc, g, num_steps=num_steps, verbose=False, device=device, s_churn=0.0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(step_seed))
+    sampler.noise_fn = lambda x: torch.randn(x.shape, generator=gen, device=x.device, dtype=x.dtype)
+    if sampler_hook is not None:
+        sampler_hook(sampler)
+    kw = {} if guider == 0 else dict(c2w=vd["c2w"].to(device), K=Ks[frames].to(device), input_frame_mask=mask.to(device))
+    return sampler(lambda x, s, c: den(denoise_net, x, s, c, num_frames=T), noise.to(device).clone(), scale=cfg,
+                   cond=cond, uc=uc, verbose=False, **kw)
+
+
+def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: torch.Tensor, Ks: torch.Tensor,
+                   input_ids: Sequence[int], *, clip_token: torch.Tensor | None = None, clip_fn: Callable | None = None,
+                   T: int = 21, num_steps: int = 50, cfg: float = 2.0, cfg_min: float = 1.2, guider: int = 1,
+                   camera_scale: float = 2.0, seed: int = 23, chunk_strategy: str = "interp",
+                   first_pass_strategy: str = "gt", device=None, group=None, ae=None, handoff: str = "latent",
+                   plan: TrajectoryPlan | None = None, timers: dict | None = None,
+                   sampler_hook: Callable | None = None) -> dict:
+    """Generate every non-input frame of a trajectory.  `denoise_net(x, t, cond, num_frames=T)` is the network call
+    (`SGMWrapper(model)`); `input_latents` (n_in,4,h,w) are the VAE-encoded input views (x 0.18215), frame ids
+    `input_ids` index `c2ws` (n,4,4) / `Ks` (n,3,3).  Returns, on rank 0, {"latents": (n,4,h,w) in frame order,
+    "frame_ids", "plan", ["rgb"]}; other ranks get {"plan"} only."""
+    rank, world = _rank_world(group)
+    device = torch.device(device) if device is not None else input_latents.device
+    h, w = input_latents.shape[-2:]
+    plan = plan or plan_trajectory(c2ws, input_ids, T, chunk_strategy, first_pass_strategy)
+    tok = (lambda ids: clip_token) if clip_fn is None else clip_fn
+    assert clip_fn is not None or clip_token is not None, "a CLIP token (or clip_fn) is required"
+
+    # initial noise: ONE CPU stream, seeded once per scene, drawn in plan order for EVERY window (eval.py:1294-1295,1450)
+    g0 = torch.Generator(device="cpu")
+    g0.manual_seed(int(seed))
+    n_win = len(plan.pass1) + len(plan.pass2)
+    noises = [torch.randn((plan.T, 4, h, w), generator=g0) for _ in range(n_win)]
+
+    def step_seed(win):  # per-window device stream: independent of rank and of execution order
+        return (int(seed) * 1000003 + 7919 * (win.global_index + 1)) & 0x7FFFFFFFFFFF
+
+    latents_of = {fid: input_latents[i].to(device) for i, fid in enumerate(plan.input_ids)}
+    common = dict(hw=(h, w), num_steps=num_steps, cfg=cfg, cfg_min=cfg_min, guider=guider, camera_scale=camera_scale,
+                  device=device, sampler_hook=sampler_hook)
+
+    def mark(name):
+        if timers is not None:
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            import time
+            timers[name] = time.perf_counter()
+
+    def handoff_latent(z):  # (k,4,h,w) generated latents -> what the next window conditions on
+        if handoff == "rgb" and ae is not None:
+            return ae.encode(ae.decode(z))
+        return z
+
+    mark("start")
+    # ------------------------------------------------------------------ pass 1
+    mine1 = list(range(len(plan.pass1))) if world == 1 else (
+        ([i for i in range(len(plan.pass1))] if rank == 0 else []) if plan.pass1_serial
+        else shard_windows(len(plan.pass1), rank, world))
+    got_ids, got_lat = [], []
+    for i in mine1:
+        win = plan.pass1[i]
+        z = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index], step_seed=step_seed(win),
+                       clip_token=tok(win.source_ids), **common)
+        zt = handoff_latent(z[win.target_slots])
+        for fid, lat in zip(win.target_ids, zt):
+            latents_of[fid] = lat  # a dependent strategy's next window on this rank may read it
+            got_ids.append(fid)
+            got_lat.append(lat)
+    mark("pass1")
+    # ------------------------------------------------------------------ exchange: one all-gather of the anchors
+    counts = [0] * world
+    for i, win in enumerate(plan.pass1):
+        owner = 0 if (world == 1 or plan.pass1_serial) else i % world
+        counts[owner] += len(win.target_ids)
+    local = torch.stack(got_lat) if got_lat else torch.zeros((0, 4, h, w), device=device)
+    parts = _all_gather_padded(local.to(device=device, dtype=torch.float32), counts[rank], max(max(counts), 1), group)
+    owner_ids = [[] for _ in range(world)]
+    for i, win in enumerate(plan.pass1):
+        owner_ids[0 if (world == 1 or plan.pass1_serial) else i % world].extend(win.target_ids)
+    for r in range(world):
+        for j, fid in enumerate(owner_ids[r]):
+            latents_of[fid] = parts[r][j]
+    mark("exchange")
+    # ------------------------------------------------------------------ pass 2: independent windows, sharded
+    mine2 = shard_windows(len(plan.pass2), rank, world)
+    outs = {}
+    for i in mine2:
+        win = plan.pass2[i]
+        outs[i] = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index],
+                             step_seed=step_seed(win), clip_token=tok(win.source_ids), **common)
+    mark("pass2")
+    # ------------------------------------------------------------------ gather to rank 0, round by round
+    rounds = (len(plan.pass2) + world - 1) // world
+    collected = {}
+    for r in range(rounds):
+        i = r * world + rank
+        mine = outs.get(i)
+        if world == 1:
+            if mine is not None:
+                collected[i] = mine
+            continue
+        send = mine if mine is not None else torch.zeros((plan.T, 4, h, w), device=device)
+        bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        dist.gather(send.contiguous(), bufs, dst=0, group=group)
+        if rank == 0:
+            for rr in range(world):
+                if r * world + rr < len(plan.pass2):
+                    collected[r * world + rr] = bufs[rr]
+    mark("gather")
+    if rank != 0:
+        return {"plan": plan}
+    n = c2ws.shape[0]
+    final = torch.zeros((n, 4, h, w), device=device)
+    filled = torch.zeros(n, dtype=torch.bool)
+    for fid in plan.input_ids + plan.anchor_ids:
+        final[fid] = latents_of[fid]
+        filled[fid] = True
+    for i, win in enumerate(plan.pass2):
+        z = collected[i]
+        for fid, slot in zip(win.target_ids, win.target_slots):
+            final[fid] = z[slot]
+            filled[fid] = True
+    assert bool(filled.all()), f"frames never generated: {torch.nonzero(~filled).flatten().tolist()}"
+    res = {"latents": final, "frame_ids": list(range(n)), "plan": plan}
+    if ae is not None:
+        res["rgb"] = ae.decode(final)
+        mark("decode")
+    return res

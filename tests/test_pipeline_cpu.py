@@ -1,0 +1,124 @@
+"""Config-4 driver (`seva.pipeline`): plan coverage of the 168-view orbit and, on gloo with two ranks, that a
+SHARDED run of the two-pass trajectory reproduces the single-process run bit for bit (per-window RNG, anchor exchange,
+round-robin gather).  The HIP operators are replaced by tests/fake_ops.py (host logic only; no GPU here) and the network
+by a cheap deterministic stand-in -- what is under test is the orchestration, not the denoiser."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _patch_cpu(monkeypatch=None):
+    """Main process: through pytest's monkeypatch (undone after the test); spawned workers: plain setattr."""
+    import fake_ops
+    import seva.ops as ops
+    from seva import geometry
+    from seva import sampling as S
+    put = setattr if monkeypatch is None else monkeypatch.setattr
+    for name in dir(fake_ops):
+        if not name.startswith("_") and callable(getattr(fake_ops, name)) and hasattr(ops, name):
+            put(ops, name, getattr(fake_ops, name))
+    put(S, "_need_gpu", lambda *a: None)
+    put(geometry, "_compute_device", lambda *a: torch.device("cpu"))
+
+
+def _scene(n=168, hw=8):
+    from seva import synthetic as synth
+    c2ws = synth.orbit_c2w(n)
+    Ks = synth.default_K(n)
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, 4, hw, hw, generator=g)
+    tok = torch.randn(1024, generator=g)
+    return c2ws, Ks, lat, tok / tok.norm()
+
+
+def _fake_net(x, t, cond, num_frames):
+    """Deterministic, frame-coupled stand-in for SGMWrapper(model): depends on x, the timestep index, the Pluecker
+    maps, the mask channel and (through the frame mean) on every frame of the window."""
+    n = x.shape[0]
+    xs = x.view(n // num_frames, num_frames, *x.shape[1:])
+    mix = xs.mean(1, keepdim=True).expand_as(xs).reshape_as(x)
+    return 0.3 * x + 0.2 * mix + 0.05 * cond["concat"][:, 1:5] + 0.01 * cond["concat"][:, :1] + 1e-4 * t.view(-1, 1, 1, 1).float()
+
+
+def _run(group=None, **kw):
+    from seva import pipeline
+    c2ws, Ks, lat, tok = _scene()
+    return pipeline.run_trajectory(_fake_net, lat, c2ws, Ks, [0], clip_token=tok, T=21, num_steps=3, seed=23,
+                                   device="cpu", group=group, **kw)
+
+
+def test_plan_covers_the_168_view_orbit():
+    """1 input + 167 targets, T=21, `interp`: 20 anchors, 1 first-pass window, 10 second-pass windows whose neighbours share
+    their boundary anchor (reference planner facts), every frame generated exactly once."""
+    from seva import pipeline
+    c2ws, _, _, _ = _scene()
+    plan = pipeline.plan_trajectory(c2ws, [0], T=21)
+    assert len(plan.anchor_ids) == 20 and len(plan.pass1) == 1 and len(plan.pass2) == 10
+    assert plan.anchor_ids == sorted(set(plan.anchor_ids)) and plan.anchor_ids[-1] == 167 and 0 not in plan.anchor_ids
+    assert not plan.pass1_serial
+    gen = [f for w in plan.pass1 + plan.pass2 for f in w.target_ids]
+    assert sorted(gen) == list(range(1, 168))
+    for a, b in zip(plan.pass2[:-1], plan.pass2[1:]):
+        assert a.source_ids[-1] == b.source_ids[0]  # the shared "overlap" anchor
+    for w in plan.pass1 + plan.pass2:
+        assert len(w.slot_frame) == 21 and all(w.slot_is_input[s] for s in w.source_slots)
+        assert [w.slot_frame[s] for s in w.target_slots] == w.target_ids
+    assert [w.global_index for w in plan.pass1 + plan.pass2] == list(range(11))
+
+
+def test_single_process_trajectory_is_deterministic_and_window_order_independent(monkeypatch):
+    _patch_cpu(monkeypatch)
+    a = _run()
+    b = _run()
+    assert torch.equal(a["latents"], b["latents"]) and torch.isfinite(a["latents"]).all()
+    assert a["latents"].shape == (168, 4, 8, 8)
+    # input frame untouched, anchors = pass-1 output
+    _, _, lat, _ = _scene()
+    assert torch.equal(a["latents"][0], lat[0])
+    assert float(a["latents"][1:].abs().mean()) > 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, first_pass):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _patch_cpu()
+    timers = {}
+    res = _run(first_pass_strategy=first_pass, timers=timers)
+    q.put((rank, res["latents"].numpy() if "latents" in res else None, sorted(timers)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("first_pass", ["gt", "gt-nearest"])
+def test_two_rank_sharded_trajectory_equals_sequential(first_pass, monkeypatch):
+    from conftest import PKG
+    here = os.path.dirname(os.path.abspath(__file__))
+    os.environ["PYTHONPATH"] = os.pathsep.join([PKG, here, os.environ.get("PYTHONPATH", "")])
+    _patch_cpu(monkeypatch)
+    ref = _run(first_pass_strategy=first_pass)["latents"]
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, first_pass)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1][1] is None  # only rank 0 assembles the trajectory
+    got = torch.from_numpy(res[0][1])
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert res[0][2] == ["exchange", "gather", "pass1", "pass2", "start"]
