@@ -78,8 +78,19 @@ typedef struct seva_gemm_desc {
   /* conv mode: 1 = zero padding only at the bottom / right edge (taps start AT pixel (stride*oy, stride*ox)); the
    * stride-2 Downsample2D of the diffusers VAE encoder pads (0,1,0,1).  0 = symmetric pad 1 (every UNet conv). */
   int32_t pad_br_only;
+  /* seva_gemm_fp8 only (NULL / 0 for seva_gemm_f16): */
+  const void* w_exp;     /* uint8 [N]: E8M0 scale byte 127 + e[n]; weight row n holds e4m3(w[n] * 2^-e[n]) */
+  void* out_f8;          /* GEGLU epilogue: e4m3 [M][ldo8] (saturating), the next fp8 GEMM's A operand; or NULL */
+  int64_t ldo8;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
+/* BASELINE config 5 ("fp8 weights, CDNA4 fp8 MFMA"): the same operator with BOTH operands in OCP e4m3 (a: [M][lda]
+ * bytes or an NHWC e4m3 image, w: [N][K] bytes) on v_mfma_scale_f32_16x16x128_f8f6f4 with fp32 accumulation; the
+ * per-output-channel power-of-two weight scale enters as the MFMA's E8M0 block scale, so the accumulator holds the
+ * de-quantised product and bias / row_add / residual / GEGLU / col_scale behave exactly as in seva_gemm_f16.
+ * K % 128 == 0 (conv: cin % 128 == 0), N % 16 == 0, no fused upsample.  The reference keeps bf16 weights
+ * (seva/utils.py:50-53): this is a separate precision mode, reported separately from the f16 parity mode. */
+int seva_gemm_fp8(const seva_gemm_desc* d, seva_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Scaled-dot-product attention, head dim 64, no mask, fp16 in/out, fp32 softmax.
@@ -135,12 +146,18 @@ typedef struct seva_groupnorm_desc {
    * the ResBlock's 1x1 skip convolution (seva/modules/layers.py:137), written in the same pass instead of by a
    * separate seva_cast_concat_f16 read of both sources.  NULL = off. */
   void* raw_f16;
+  /* optional e4m3 output (saturating), same layout: the A operand of seva_gemm_fp8 / an fp8 conv.  When set, out_f16
+   * may be NULL. */
+  void* out_f8;
 } seva_groupnorm_desc;
 int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
 
 /* LayerNorm over the last dim, fp32 in, f16 out (nn.LayerNorm, transformer.py:102-104,124,141-143). */
 int seva_layernorm_f16(const float* x, const float* gamma, const float* beta, void* out_f16,
                        int64_t rows, int32_t c, float eps, seva_stream_t stream);
+/* Same normalisation with OCP e4m3 output (saturating at +-448): the A operand of seva_gemm_fp8. */
+int seva_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* out_f8, int64_t rows,
+                       int32_t c, float eps, seva_stream_t stream);
 
 /* Row softmax: out[r][c] = softmax_c(x[r][c] * scale) as f16 for c < cols; columns cols..cols_pad-1
  * of `out` are written as 0 (so `out` can be the K-padded A operand of the following P*V GEMM).

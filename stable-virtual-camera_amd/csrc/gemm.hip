@@ -35,7 +35,37 @@ __device__ __forceinline__ void wait_vm() {
 // stacked 4x1 (32 rows x the full tile width each), every wave loads its 32 x K fragment set once
 // (<= 80 VGPRs) and only the weight tile is staged through LDS: 44 % fewer LDS-DMA bytes per FLOP for
 // the ds1 QKV / GEGLU projections, whose time was 15-23 % A re-staging (SEVA_GEMM_DBG=128).
-template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT>
+//
+// FP8 (BASELINE config 5): both operands are OCP e4m3 bytes and the product runs on the block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 (2x the f16 MFMA rate, half the operand bytes per FLOP).  A K-tile is still 128-byte
+// LDS rows -- now 128 e4m3 elements -- so staging, swizzle and fragment reads are byte-for-byte those of the f16 kernel
+// (pointers and K / lda / cin count 2-byte units); the two 16-byte fragment reads of a K-tile form ONE 32-byte MFMA
+// operand (k order inside the tile is permuted identically for both operands, which a dot product does not see).
+// The per-output-channel weight scale is a power of two, 2^e[n], handed to the MFMA as the E8M0 block scale of the
+// weight operand (every k-block of row n carries 127 + e[n]; measured: tools/micro/mfma_fp8_scale_map2.hip), the
+// activation operand has unit scale: the accumulator holds the de-quantised product, so every epilogue
+// (residual-in-accumulator, GEGLU, column scale) is the f16 kernel's.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+template <int OPSEL>
+__device__ __forceinline__ f32x4 mfma_f8_sel(half8_t w_lo, half8_t w_hi, half8_t a_lo, half8_t a_hi, f32x4 c, int wscale) {
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  const v4i_t wl = __builtin_bit_cast(v4i_t, w_lo), wh = __builtin_bit_cast(v4i_t, w_hi);
+  const v4i_t al = __builtin_bit_cast(v4i_t, a_lo), ah = __builtin_bit_cast(v4i_t, a_hi);
+  const v8i_t w = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+  const v8i_t a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0 /*e4m3*/, 0 /*e4m3*/, OPSEL, wscale, 0, 0x7F7F7F7F);
+}
+// scale byte (j & 3) of the packed per-lane scale word of block j
+__device__ __forceinline__ f32x4 mfma_f8(int j, half8_t w_lo, half8_t w_hi, half8_t a_lo, half8_t a_hi, f32x4 c, int wscale) {
+  switch (j & 3) {
+    case 0: return mfma_f8_sel<0>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+    case 1: return mfma_f8_sel<1>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+    case 2: return mfma_f8_sel<2>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+    default: return mfma_f8_sel<3>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+  }
+}
+
+template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int dbg = DBGK ? p.dbg : 0;
   constexpr int WM = ASTAT ? BM / 4 : BM / 2, WN = ASTAT ? BN : BN / 2;  // per-wave tile
@@ -64,6 +94,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   };
   // first output feature (relative to n0 + wn*WN) of block j for lane group fg
   auto feat_of = [](int j, int fg) { return j < NJP ? 32 * (j >> 1) + 8 * fg + 4 * (j & 1) : 16 * j + 4 * fg; };
+
+  // FP8: weight row (relative to n0 + wn*WN) that MFMA row `r` of block j reads (the fragment-read row of b_frag_off)
+  auto wrow_of = [](int j, int r) { return j < NJP ? 32 * (j >> 1) + 4 * (j & 1) + 8 * (r >> 2) + (r & 3) : 16 * j + r; };
+  constexpr int NSC = (NJ + 3) / 4;  // packed scale words per lane
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [A buf0][A buf1][B buf0][B buf1]
@@ -213,6 +247,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const unsigned bias_slot_u32 = lds_base_u32 + 2 * (A_BYTES + B_BYTES) + wave * 1024;
   const char* const bias_slot = smem + 2 * (A_BYTES + B_BYTES) + wave * 1024;
   auto bias_par = [&](int tn) { return ASTAT ? ((tn - tn_begin) & 1) * 4096 : 0; };
+  // FP8: per-wave 1 KiB slot behind the bias slots for the tile's weight-scale bytes (lane L brings 16 of them)
+  constexpr int BIAS_SLOTS = ASTAT ? 8192 : 4096;
+  const unsigned wexp_slot_u32 = lds_base_u32 + 2 * (A_BYTES + B_BYTES) + BIAS_SLOTS + wave * 1024;
+  const char* const wexp_slot = smem + 2 * (A_BYTES + B_BYTES) + BIAS_SLOTS + wave * 1024;
+  auto stage_wexp = [&](int tn) {
+    int64_t f = (int64_t)tn * BN + 16 * lane;
+    if (f > p.N - 16) f = p.N - 16;  // N % 16 == 0 (host-checked): in-range lanes are never shifted
+    glds16_raw(p.w_exp + f, wexp_slot_u32);
+  };
   auto stage_async = [&](int buf, int kt) {
     const unsigned la = lds_base_u32 + buf * A_BYTES + wave * (BM / 4) * 128;
     const unsigned lb = lds_base_u32 + 2 * A_BYTES + buf * B_BYTES + wave * (BN / 4) * 128;
@@ -285,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   set_b_tile(tn_begin);
   if (ASYNC) {
     if (p.bias) stage_bias(tn_begin);
+    if (FP8) stage_wexp(tn_begin);
     stage_async(0, 0);
     if (nk > 1) stage_async(1, 1);
   } else {
@@ -324,6 +368,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     } else {
       __syncthreads();  // stage 0 of this tile (and the residual) has landed (vmcnt(0) + barrier)
     }
+    // FP8: E8M0 scale bytes of this lane's weight rows, 4 blocks per word.  ASYNC schedule: out of the wave's LDS slot
+    // (they rode in with stage 0, like the bias: no compiler-visible global load may sit in that loop); otherwise
+    // plain global byte loads.
+    int wsc[FP8 ? NSC : 1];
+    if constexpr (FP8) {
+#pragma unroll
+      for (int w = 0; w < NSC; ++w) wsc[w] = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = wn * WN + wrow_of(j, lane & 15);
+        int b;
+        if (ASYNC) {
+          b = *(const unsigned char*)(wexp_slot + row);
+        } else {
+          int64_t n = n0 + row;
+          if (n >= p.N) n = p.N - 1;
+          b = p.w_exp[n];
+        }
+        wsc[j >> 2] |= b << (8 * (j & 3));
+      }
+      if (ASYNC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     auto ktile = [&](int kt) {
       const int cur = kt & 1;
       if (ASYNC) {
@@ -335,7 +401,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       const char* const tb = lds_b + cur * B_BYTES;
       // all 16 fragment reads of the K-tile are issued first: the second k-step's fragments land
       // while the first k-step's MFMAs execute (the compiler waits with a counted lgkmcnt)
-      if constexpr (ASTAT) {
+      if constexpr (ASTAT && FP8) {
+        half8_t bfr[2][NJ];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bfr[s2][j] = *(const half8_t*)(tb + b_frag_off(s2, j));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = mfma_f8(j, bfr[0][j], bfr[1][j], areg[i][2 * kt], areg[i][2 * kt + 1], acc[i][j], wsc[j >> 2]);
+      } else if constexpr (ASTAT) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           half8_t bfr[NJ];
@@ -366,6 +443,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bf[s][j]));
         }
       }
+      if constexpr (FP8) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = mfma_f8(j, bf[0][j], bf[1][j], af[0][i], af[1][i], acc[i][j], wsc[j >> 2]);
+      } else
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (!(dbg & 2)) {
@@ -433,6 +517,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       set_b_tile(tn + 1);
       if (ASYNC) {
         if (p.bias) stage_bias(tn + 1);
+        if (FP8) stage_wexp(tn + 1);
         stage_async(0, 0);
         if (nk > 1) stage_async(1, 1);
       } else {
@@ -442,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // ASYNC bookkeeping: S_ST is exact only for an interior tile (every guarded store executes) with
     // 16-byte stores; anything else falls back to vmcnt(0)-strength waits (a smaller count is always safe)
     stores_flying = ASYNC && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldo16 & 7) == 0 && !p.out_f32 &&
-                    tn + 1 < tn_end;
+                    !(FP8 && p.out_f8 && p.out_f16) && tn + 1 < tn_end;  // (f8 + f16 together: twice the stores)
 
     // ---- epilogue: lane holds features f..f+3 (rows of D) of token m (column of D) ----
     if constexpr (EPI == 0 && PAIRED) {
@@ -579,16 +664,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
                          (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
             *(half8_t*)(p.out_f16 + m * p.ldo16 + fo) = h;
           }
+          if constexpr (FP8) {
+            if (p.out_f8) {  // e4m3 hidden activations, saturating (8 consecutive features = one 8-byte store)
+              const int lo = pack_fp8x4(o0[0], o0[1], o0[2], o0[3]);
+              const int hi = pack_fp8x4(o1[0], o1[1], o1[2], o1[3]);
+              typedef int v2i_t __attribute__((ext_vector_type(2)));
+              *(v2i_t*)(p.out_f8 + m * p.ldo8 + fo) = v2i_t{lo, hi};
+            }
+          }
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false>
+template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false, bool FP8 = false>
 int launch_p(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 2 * ((ASTAT ? 0 : BM) + BN) * 128 + (ASTAT ? 8192 : PAIRED ? 4096 : 0);  // + bias slots (ASYNC)
-  constexpr bool DBG_BUILD = !ASTAT;  // the ablation instantiation only exists for the staged-A kernels
+  // + bias slots (ASYNC) + weight-scale slots (FP8 ASYNC)
+  constexpr int lds = 2 * ((ASTAT ? 0 : BM) + BN) * 128 + (ASTAT ? 8192 : PAIRED ? 4096 : 0) + (FP8 && PAIRED ? 4096 : 0);
+  constexpr bool DBG_BUILD = !ASTAT && !FP8;  // the ablation instantiation only exists for the staged-A f16 kernels
   // the dynamic-LDS attribute is per device: one bit per device ordinal and instantiation (a second GPU in the
   // same process would otherwise launch 72-80 KB kernels without it)
   static std::atomic<uint64_t> attr_devs{0};
@@ -596,7 +690,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (DBG_BUILD)
       (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED, false>,
@@ -648,43 +742,57 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
       return seva_check_launch("gemm_kernel");
     }
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT>), dim3((unsigned)nb), dim3(256), lds, s, args);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8>), dim3((unsigned)nb), dim3(256), lds, s, args);
   return seva_check_launch("gemm_kernel");
 }
 
-template <int BM, int BN, int MODE, int EPI>
+template <int BM, int BN, int MODE, int EPI, bool FP8 = false>
 int launch(const GemmArgs& a, hipStream_t s) {
   // knob gemm_astat = 0 (SEVA_GEMM_ASTAT=0) disables the A-in-registers variant (benchmarking)
   const bool astat_on = g_seva_knobs.gemm_astat != 0;
   const bool dbg_run = g_seva_knobs.gemm_dbg >= 0 || g_seva_knobs.gemm_stagger >= 0;
+  const bool half_out = a.out_f16 || (FP8 && a.out_f8);  // 2-byte (or e4m3) outputs only: ASYNC schedule
+  // (the A-in-registers variant is f16-only: with both k-steps' fragments live for one 128-deep MFMA it spills)
   if constexpr (EPI == 1) {
-    if constexpr (BM == 128) {
-      if (astat_on && !dbg_run && a.K <= 320 && a.out_f16 && !a.out_f32) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
+    if constexpr (BM == 128 && !FP8) {
+      if (astat_on && !dbg_run && a.K <= 320 && half_out && !a.out_f32) return launch_p<BM, BN, MODE, EPI, true, true, FP8>(a, s);
     }
-    return launch_p<BM, BN, MODE, EPI, true>(a, s);
+    return launch_p<BM, BN, MODE, EPI, true, false, FP8>(a, s);
   } else {
     if constexpr (MODE == 0 && BN >= 128) {
       if (a.out_f16 && !a.out_f32 && !a.residual) {
-        if constexpr (BM == 128) {
-          if (astat_on && !dbg_run && a.K <= 320) return launch_p<BM, BN, MODE, EPI, true, true>(a, s);
+        if constexpr (BM == 128 && !FP8) {
+          if (astat_on && !dbg_run && a.K <= 320) return launch_p<BM, BN, MODE, EPI, true, true, FP8>(a, s);
         }
-        return launch_p<BM, BN, MODE, EPI, true>(a, s);
+        return launch_p<BM, BN, MODE, EPI, true, false, FP8>(a, s);
       }
     }
-    return launch_p<BM, BN, MODE, EPI, false>(a, s);
+    return launch_p<BM, BN, MODE, EPI, false, false, FP8>(a, s);
   }
 }
 
 }  // namespace
 
-extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
+namespace {
+template <bool FP8>
+int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   SEVA_REQUIRE(d != nullptr, "gemm: null desc");
   SEVA_REQUIRE(d->a && d->w, "gemm: null operand");
   SEVA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%lld N=%lld K=%lld",
                (long long)d->M, (long long)d->N, (long long)d->K);
-  SEVA_REQUIRE(d->K % BK == 0, "gemm: K=%lld not a multiple of 64", (long long)d->K);
+  constexpr int KU = FP8 ? 2 : 1;  // e4m3 elements per 2-byte unit of the kernel's K / lda / cin arithmetic
+  SEVA_REQUIRE(d->K % (BK * KU) == 0, "gemm: K=%lld not a multiple of %d", (long long)d->K, BK * KU);
   SEVA_REQUIRE(d->N % 4 == 0, "gemm: N=%lld not a multiple of 4", (long long)d->N);
-  SEVA_REQUIRE(d->out_f32 || d->out_f16, "gemm: no output");
+  SEVA_REQUIRE(d->out_f32 || d->out_f16 || (FP8 && d->out_f8), "gemm: no output");
+  if (FP8) {
+    SEVA_REQUIRE(d->w_exp != nullptr, "gemm fp8: w_exp (per-channel E8M0 scale bytes) is required");
+    SEVA_REQUIRE(d->N % 16 == 0 && d->N > 32, "gemm fp8: N=%lld must be a multiple of 16 and > 32", (long long)d->N);
+    SEVA_REQUIRE(!d->upsample, "gemm fp8: the fused-upsample conv stays on the f16 kernel");
+    SEVA_REQUIRE(!d->out_f8 || (d->epilogue == 1 && d->ldo8 % 8 == 0 && (uintptr_t)d->out_f8 % 8 == 0),
+                 "gemm fp8: out_f8 is the GEGLU epilogue's output (row pitch and pointer multiples of 8)");
+  } else {
+    SEVA_REQUIRE(!d->out_f8 && !d->w_exp, "gemm f16: out_f8 / w_exp belong to seva_gemm_fp8");
+  }
   SEVA_REQUIRE(d->mode == 0 || d->mode == 1, "gemm: bad mode %d", d->mode);
   SEVA_REQUIRE(d->epilogue == 0 || d->epilogue == 1, "gemm: bad epilogue %d", d->epilogue);
   SEVA_REQUIRE(!d->row_add || d->rows_per_group > 0, "gemm: row_add needs rows_per_group");
@@ -702,8 +810,10 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   a.residual = d->residual;
   a.out_f32 = d->out_f32;
   a.out_f16 = (half_t*)d->out_f16;
-  a.M = d->M; a.N = d->N; a.K = d->K;
-  a.lda = d->lda; a.ldr = d->ldr; a.ldo32 = d->ldo32; a.ldo16 = d->ldo16;
+  a.out_f8 = (uint8_t*)d->out_f8;
+  a.w_exp = (const uint8_t*)d->w_exp;
+  a.M = d->M; a.N = d->N; a.K = d->K / KU;
+  a.lda = d->lda / KU; a.ldr = d->ldr; a.ldo32 = d->ldo32; a.ldo16 = d->ldo16; a.ldo8 = d->ldo8;
   a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
   a.col_scale = d->col_scale;
   a.col_scale_n = d->col_scale_n;
@@ -714,7 +824,7 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   a.ldra = d->ld_row_add > 0 ? d->ld_row_add : d->N;
   SEVA_REQUIRE(a.ldra % 4 == 0, "gemm: ld_row_add must be a multiple of 4");
   if (d->mode == 1) {
-    SEVA_REQUIRE(d->cin > 0 && d->cin % 64 == 0, "conv: cin=%d not a multiple of 64", d->cin);
+    SEVA_REQUIRE(d->cin > 0 && d->cin % (64 * KU) == 0, "conv: cin=%d not a multiple of %d", d->cin, 64 * KU);
     SEVA_REQUIRE(d->K == 9LL * d->cin, "conv: K=%lld != 9*cin", (long long)d->K);
     SEVA_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
     SEVA_REQUIRE(!(d->upsample && d->stride != 1), "conv: upsample needs stride 1");
@@ -724,19 +834,21 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
                  "conv: output %dx%d inconsistent with input %dx%d stride %d up %d pad_br_only %d", d->oh, d->ow,
                  d->ih, d->iw, d->stride, d->upsample, d->pad_br_only);
     SEVA_REQUIRE(d->M == (int64_t)d->n * d->oh * d->ow, "conv: M != n*oh*ow");
-    a.n = d->n; a.ih = d->ih; a.iw = d->iw; a.cin = d->cin; a.oh = d->oh; a.ow = d->ow;
+    a.n = d->n; a.ih = d->ih; a.iw = d->iw; a.cin = d->cin / KU; a.oh = d->oh; a.ow = d->ow;
     a.stride = d->stride; a.upsample = d->upsample;
     a.pad_lo = d->pad_br_only ? 0 : 1;
   } else {
-    SEVA_REQUIRE(d->lda >= d->K && d->lda % 8 == 0, "gemm: lda=%lld invalid", (long long)d->lda);
+    SEVA_REQUIRE(d->lda >= d->K && d->lda % (8 * KU) == 0, "gemm: lda=%lld invalid", (long long)d->lda);
   }
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
   // algorithmic HBM bytes: A (conv: the NHWC image) and W read once, residual read once, each output written once
   const double a_elems = d->mode == 1 ? (double)d->n * d->ih * d->iw * d->cin : (double)d->M * (double)d->K;
   const double n_out = d->epilogue == 1 ? (double)d->N / 2 : (double)d->N;
-  const double alg_bytes = 2.0 * a_elems + 2.0 * (double)d->N * (double)d->K + (d->bias ? 4.0 * (double)d->N : 0.0) +
-                           (double)d->M * n_out * ((d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) + (d->out_f16 ? 2.0 : 0.0));
+  const double esz = FP8 ? 1.0 : 2.0;
+  const double alg_bytes = esz * a_elems + esz * (double)d->N * (double)d->K + (d->bias ? 4.0 * (double)d->N : 0.0) +
+                           (double)d->M * n_out * ((d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) +
+                                                   (d->out_f16 ? 2.0 : 0.0) + (d->out_f8 ? 1.0 : 0.0));
   SevaProfScope prof(d->mode == 1 ? 1 : 0, flops, s, alg_bytes);
   if (d->epilogue == 1) {
     SEVA_REQUIRE(d->N % 64 == 0, "geglu: N=%lld not a multiple of 64", (long long)d->N);
@@ -744,6 +856,21 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
     SEVA_REQUIRE(!d->out_f16 || d->ldo16 % 8 == 0, "geglu: f16 row pitch must be a multiple of 8");
   }
   const bool narrow = d->N <= 32;
+  if constexpr (FP8) {
+    // e4m3 operands: the K >= 640 GEMMs / cin >= 640 convs of the ds2..ds8 levels.  Same tile-shape heuristics.
+    bool half_m8 = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
+    if (g_seva_knobs.gemm_bm > 0) half_m8 = g_seva_knobs.gemm_bm == 64;
+    bool wide8 = d->N % 160 == 0;
+    if (g_seva_knobs.gemm_bn > 0) wide8 = g_seva_knobs.gemm_bn == 160;
+    if (d->epilogue == 1) return half_m8 ? launch<64, 128, 0, 1, true>(a, s) : launch<128, 128, 0, 1, true>(a, s);
+    // 128-row tiles are 128 wide only: 128x160 with both k-steps' fragments live exceeds 256 VGPRs (spills)
+    if (d->mode == 0) {
+      if (half_m8) return wide8 ? launch<64, 160, 0, 0, true>(a, s) : launch<64, 128, 0, 0, true>(a, s);
+      return launch<128, 128, 0, 0, true>(a, s);
+    }
+    if (half_m8) return wide8 ? launch<64, 160, 1, 0, true>(a, s) : launch<64, 128, 1, 0, true>(a, s);
+    return launch<128, 128, 1, 0, true>(a, s);
+  } else {
 #ifdef SEVA_EXPERIMENTAL
   // experimental library only (make exp -> build_ab/libseva_hip_exp.so, loaded through SEVA_HIP_LIB for A/B runs): knob
   // gemm_cfg = 1/2/3 (ring variants, gemm_ring.hip), 4 (256x256 phased, gemm_phase.hip).  None of them wins on any shape of
@@ -776,4 +903,12 @@ extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) {
   if (narrow) return launch<128, 32, 1, 0>(a, s);
   if (half_m) return wide ? launch<64, 160, 1, 0>(a, s) : launch<64, 128, 1, 0>(a, s);
   return wide ? launch<128, 160, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
+  }  // !FP8
 }
+}  // namespace
+
+extern "C" int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream) { return gemm_entry<false>(d, stream); }
+
+// e4m3 x e4m3 -> fp32 on the block-scaled MFMA (BASELINE config 5): A and W are OCP e4m3 bytes, K counts e4m3 elements
+// (K % 128 == 0; conv: cin % 128 == 0), w_exp[n] = 127 + e[n] is the weight row's power-of-two scale.
+extern "C" int seva_gemm_fp8(const seva_gemm_desc* d, seva_stream_t stream) { return gemm_entry<true>(d, stream); }

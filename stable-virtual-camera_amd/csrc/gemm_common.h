@@ -12,8 +12,10 @@ struct SevaGemmArgs {
   const float* residual;
   float* out_f32;
   half_t* out_f16;
-  int64_t M, N, K;
-  int64_t lda, ldr, ldo32, ldo16;
+  uint8_t* out_f8;        // FP8 kernels, GEGLU epilogue: e4m3 hidden activations (the next fp8 GEMM's A operand)
+  const uint8_t* w_exp;   // FP8 kernels: per-output-channel E8M0 scale byte (127 + e): weight row n is q_n * 2^e
+  int64_t M, N, K;        // FP8 kernels: K, lda, cin count 2-byte units (= pairs of e4m3 elements)
+  int64_t lda, ldr, ldo32, ldo16, ldo8;
   int64_t rows_per_group, ldra;
   int32_t n, ih, iw, cin, oh, ow, stride, upsample;
   int32_t pad_lo;    // conv: zero rows/cols before pixel 0 (1, or 0 for bottom/right-only padding)

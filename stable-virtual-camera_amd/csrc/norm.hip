@@ -25,7 +25,8 @@ struct GnArgs {
   const float* dense;
   const float* dense_w;
   const float* dense_b;
-  half_t* out;
+  half_t* out;      // f16 output (may be null when out8 is set)
+  uint8_t* out8;    // optional: e4m3 output (A operand of an fp8 GEMM / conv), same layout
   half_t* raw_out;  // optional: plain f16 copy of the (concatenated) input, same layout as out
   float* ws;
   int32_t n, hw, c1, c2, groups, dense_c, silu;
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
       for (int u = 0; u < U; ++u) {
         const int pix = pix0 + u * pl_count;
         half4_t h;
+        float y4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float y = v[u][r] * a[r] + b[r];
@@ -230,9 +232,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
             y = y * m[0] + m[1];
           }
           h[r] = (half_t)y;
+          y4[r] = y;
         }
         if (pix < p_end) {
-          *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+          if (p.out) *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+          if (p.out8) *(int*)(p.out8 + ((int64_t)n * p.hw + pix) * C + c0) = pack_fp8x4(y4[0], y4[1], y4[2], y4[3]);
           if (p.raw_out) {  // the un-normalised input as f16: A operand of the ResBlock's 1x1 skip conv
             const half4_t hr = {(half_t)v[u][0], (half_t)v[u][1], (half_t)v[u][2], (half_t)v[u][3]};
             *(half4_t*)(p.raw_out + ((int64_t)n * p.hw + pix) * C + c0) = hr;
@@ -255,12 +259,12 @@ __device__ __forceinline__ float group16_sum(float v) {
 // contiguous bytes per row and a lane keeps C/64 16-byte loads in flight.
 // LN_ROWS rows are walked by one 16-lane group: gamma / beta stay in registers, the next row is prefetched.  4 for big
 // tensors (ds1 93 -> 79 us); 1 when that would leave fewer workgroups than ~4 per CU.
-template <int NV, int LN_ROWS>
+template <int NV, int LN_ROWS, bool F8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         half_t* __restrict__ out, int64_t rows,
-                                                        int c, float eps) {
+                                                        int c, float eps) {  // F8: `out` is an e4m3 byte buffer
   const int sub = threadIdx.x & 15;
   const int cq = c >> 2;
   // group g of the block owns rows base + g, base + g + 16, ... (consecutive groups touch consecutive rows per pass)
@@ -314,10 +318,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (i < cq) {
           const f32x4 g4 = HOIST ? gm[HOIST ? k : 0] : *(const f32x4*)(gamma + i * 4);
           const f32x4 b4 = HOIST ? bt[HOIST ? k : 0] : *(const f32x4*)(beta + i * 4);
-          half4_t h;
+          if constexpr (F8) {
+            float y[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (half_t)((v[k][r] - mean) * rstd * g4[r] + b4[r]);
-          *(half4_t*)(orow + i * 4) = h;
+            for (int r = 0; r < 4; ++r) y[r] = (v[k][r] - mean) * rstd * g4[r] + b4[r];
+            *(int*)((uint8_t*)out + row * c + i * 4) = pack_fp8x4(y[0], y[1], y[2], y[3]);
+          } else {
+            half4_t h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)((v[k][r] - mean) * rstd * g4[r] + b4[r]);
+            *(half4_t*)(orow + i * 4) = h;
+          }
         }
       }
     }
@@ -358,7 +369,7 @@ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream) {
   SEVA_REQUIRE(d != nullptr, "groupnorm: null desc");
-  SEVA_REQUIRE(d->x1 && d->gamma && d->beta && d->out_f16 && d->workspace, "groupnorm: null pointer");
+  SEVA_REQUIRE(d->x1 && d->gamma && d->beta && (d->out_f16 || d->out_f8) && d->workspace, "groupnorm: null pointer");
   SEVA_REQUIRE(d->n > 0 && d->hw > 0 && d->c1 > 0 && d->c2 >= 0, "groupnorm: bad shape");
   SEVA_REQUIRE(d->c2 == 0 || d->x2 != nullptr, "groupnorm: c2 > 0 needs x2");
   const int C = d->c1 + d->c2;
@@ -371,7 +382,7 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   GnArgs a{};
   a.x1 = d->x1; a.x2 = d->x2; a.gamma = d->gamma; a.beta = d->beta;
   a.dense = d->dense; a.dense_w = d->dense_w; a.dense_b = d->dense_b;
-  a.out = (half_t*)d->out_f16; a.raw_out = (half_t*)d->raw_f16; a.ws = d->workspace;
+  a.out = (half_t*)d->out_f16; a.out8 = (uint8_t*)d->out_f8; a.raw_out = (half_t*)d->raw_f16; a.ws = d->workspace;
   a.n = d->n; a.hw = d->hw; a.c1 = d->c1; a.c2 = d->c2; a.groups = d->groups;
   a.dense_c = d->dense_c; a.silu = d->silu; a.eps = d->eps;
   const int cq = C / 4;
@@ -413,26 +424,27 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   return seva_check_launch("gn_apply_kernel");
 }
 
-extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const float* beta,
-                                  void* out_f16, int64_t rows, int32_t c, float eps,
-                                  seva_stream_t stream) {
-  SEVA_REQUIRE(x && gamma && beta && out_f16, "layernorm: null pointer");
+namespace {
+template <bool F8>
+int layernorm_entry(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int32_t c, float eps,
+                    seva_stream_t stream) {
+  SEVA_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
   SEVA_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && c <= 16 * 4 * LN_MAXV,
                "layernorm: rows=%lld c=%d unsupported", (long long)rows, c);
   hipStream_t s = (hipStream_t)stream;
-  SevaProfScope prof(3, (double)rows * c * 6.0, s);
+  SevaProfScope prof(3, (double)rows * c * (F8 ? 5.0 : 6.0), s);
   const int lr = rows >= 64 * 1024 ? 4 : 1;
   const int64_t blocks = (rows + 16 * lr - 1) / (16 * lr);
   SEVA_REQUIRE(blocks <= 0x7fffffff, "layernorm: too many rows");
   const int nv = (c / 4 + 15) / 16;
-#define SEVA_LN_LAUNCH(NV)                                                                              \
-  do {                                                                                                  \
-    if (lr == 4)                                                                                        \
-      hipLaunchKernelGGL((layernorm_kernel<NV, 4>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
-                         beta, (half_t*)out_f16, rows, c, eps);                                         \
-    else                                                                                                \
-      hipLaunchKernelGGL((layernorm_kernel<NV, 1>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
-                         beta, (half_t*)out_f16, rows, c, eps);                                         \
+#define SEVA_LN_LAUNCH(NV)                                                                                  \
+  do {                                                                                                      \
+    if (lr == 4)                                                                                            \
+      hipLaunchKernelGGL((layernorm_kernel<NV, 4, F8>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
+                         beta, (half_t*)out, rows, c, eps);                                                 \
+    else                                                                                                    \
+      hipLaunchKernelGGL((layernorm_kernel<NV, 1, F8>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
+                         beta, (half_t*)out, rows, c, eps);                                                 \
   } while (0)
   if (nv <= 2) SEVA_LN_LAUNCH(2);
   else if (nv <= 5) SEVA_LN_LAUNCH(5);
@@ -440,6 +452,20 @@ extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const floa
   else SEVA_LN_LAUNCH(20);
 #undef SEVA_LN_LAUNCH
   return seva_check_launch("layernorm_kernel");
+}
+}  // namespace
+
+extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const float* beta,
+                                  void* out_f16, int64_t rows, int32_t c, float eps,
+                                  seva_stream_t stream) {
+  return layernorm_entry<false>(x, gamma, beta, out_f16, rows, c, eps, stream);
+}
+
+// same normalisation, output as OCP e4m3 bytes (saturating): A operand of seva_gemm_fp8
+extern "C" int seva_layernorm_fp8(const float* x, const float* gamma, const float* beta,
+                                  void* out_f8, int64_t rows, int32_t c, float eps,
+                                  seva_stream_t stream) {
+  return layernorm_entry<true>(x, gamma, beta, out_f8, rows, c, eps, stream);
 }
 
 extern "C" int seva_softmax_rows_f16(const float* x, int64_t ldx, void* out_f16, int64_t ldo,

@@ -61,6 +61,12 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// four floats -> four OCP e4m3 bytes (round to nearest even, saturating at +-448), byte i = value i
+__device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
+  const auto cl = [](float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); };
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // GELU with the exact (erf) definition, reference F.gelu at seva/modules/transformer.py:15.
 // erf by Abramowitz & Stegun 7.1.26: |abs error| <= 1.5e-7, branch-free, 2 transcendentals + 9 FMA-class

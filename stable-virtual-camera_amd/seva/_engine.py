@@ -30,7 +30,7 @@ from . import _native, ops
 from ._arch import Layout
 from ._native import SevaNativeError, require_cuda
 
-F16, F32 = torch.float16, torch.float32
+F16, F32, U8 = torch.float16, torch.float32, torch.uint8
 # softmax scale of head dim 64 (reference transformer.py:66-72) times log2(e): exp(x) == exp2(x * log2 e)
 QK_SCALE_LOG2E = 0.125 * 1.4426950408889634
 CIN_PAD = 64  # conv A-operand channel granularity (one K-tile per tap)
@@ -89,8 +89,17 @@ class SevaEngine:
         _native.load()
         return params[0].device
 
-    def __init__(self, model):
+    def __init__(self, model, precision: str | None = None):
+        """precision "f16" (default; the parity mode, fp16 operands / fp32 accumulation) or "fp8" (BASELINE config 5:
+        e4m3 weights AND activations on the block-scaled fp8 MFMA for every GEMM / 3x3 conv whose reduction length is a
+        multiple of 128 -- the C = 640 / 1280 levels; the C = 320 level and the small projections stay f16)."""
+        import os as _os
+
         self.device = self._resolve_device(model)
+        self.precision = precision or _os.environ.get("SEVA_PRECISION", "f16")
+        if self.precision not in ("f16", "fp8"):
+            raise ValueError(f"unknown precision {self.precision!r} (f16 | fp8)")
+        self.fp8 = self.precision == "fp8"
         self.p = model.params
         self.layout: Layout = model._layout
         self.arena = _Arena(self.device)
@@ -132,10 +141,16 @@ class SevaEngine:
         self.ctx_off: dict[str, int] = {}
         emb_total = ctx_total = 0
 
+        def q8(name, w):
+            """fp8 mode: e4m3 copy + per-row power-of-two scale bytes of an [N, K] weight whose K is a multiple of 128"""
+            if self.fp8 and w.shape[1] % 128 == 0 and w.shape[0] % 16 == 0 and w.shape[0] > 32:
+                W[name + "8"], W[name + "8e"] = ops.quantize_weight_fp8(w)
+
         def pack_attn_self(pfx):
             W[pfx + ".qkv"] = torch.cat(
                 [f16(pfx + ".to_q.weight"), f16(pfx + ".to_k.weight"), f16(pfx + ".to_v.weight")], 0
             ).contiguous()
+            q8(pfx + ".qkv", torch.cat([f32(pfx + ".to_q.weight"), f32(pfx + ".to_k.weight"), f32(pfx + ".to_v.weight")], 0))
             W[pfx + ".out.w"], W[pfx + ".out.b"] = f16(pfx + ".to_out.0.weight"), f32(pfx + ".to_out.0.bias")
 
         def pack_attn_cross(pfx):
@@ -154,6 +169,9 @@ class SevaEngine:
             wi, bi = interleave_geglu(f16(pfx + ".net.0.proj.weight"), f32(pfx + ".net.0.proj.bias"))
             W[pfx + ".w1"], W[pfx + ".b1"] = wi, bi
             W[pfx + ".w2"], W[pfx + ".b2"] = f16(pfx + ".net.2.weight"), f32(pfx + ".net.2.bias")
+            if self.fp8 and wi.shape[1] % 128 == 0:  # both or neither: the hidden activations travel as e4m3
+                q8(pfx + ".w1", interleave_geglu(f32(pfx + ".net.0.proj.weight"), f32(pfx + ".net.0.proj.bias"))[0])
+                q8(pfx + ".w2", f32(pfx + ".net.2.weight"))
 
         def pack_ln(pfx):
             W[pfx + ".g"], W[pfx + ".b"] = f32(pfx + ".weight"), f32(pfx + ".bias")
@@ -171,6 +189,11 @@ class SevaEngine:
                 W[pfx + ".conv1.b"] = f32(pfx + ".in_layers.2.bias")
                 W[pfx + ".conv2.w"] = pack_conv3x3(f32(pfx + ".out_layers.3.weight"))
                 W[pfx + ".conv2.b"] = f32(pfx + ".out_layers.3.bias")
+                if self.fp8:  # K = 9*cin ordered (ky, kx, ci): a 128-deep K-tile must not straddle taps
+                    if spec.cin % 128 == 0:
+                        q8(pfx + ".conv1.w", pack_conv3x3(f32(pfx + ".in_layers.2.weight")).float())
+                    if spec.cout % 128 == 0:
+                        q8(pfx + ".conv2.w", pack_conv3x3(f32(pfx + ".out_layers.3.weight")).float())
                 W[pfx + ".dense.w"] = f32(pfx + ".dense_emb_layers.0.weight").reshape(2 * spec.cin, -1).contiguous()
                 W[pfx + ".dense.b"] = f32(pfx + ".dense_emb_layers.0.bias")
                 emb_w.append(f16(pfx + ".emb_layers.1.weight"))
@@ -213,8 +236,8 @@ class SevaEngine:
     def _buf(self, name, shape, dtype):
         return self.arena.get(name, shape, dtype)
 
-    def _ln(self, x, pfx, rows, c):
-        out = self._buf("ln16", (rows, c), F16)
+    def _ln(self, x, pfx, rows, c, fp8=False):
+        out = self._buf("ln8", (rows, c), U8) if fp8 else self._buf("ln16", (rows, c), F16)
         ops.layernorm(x, self.W[pfx + ".g"], self.W[pfx + ".b"], out)
         return out
 
@@ -235,10 +258,18 @@ class SevaEngine:
 
     def _ff(self, x32, ln_pfx, ff_pfx, rows, c, *, residual, out_f32=None, out_f16=None, unit=1):
         """GEGLU feed-forward on LayerNorm(x32): reference transformer.py:18-34."""
+        W = self.W
+        if ff_pfx + ".w18" in W:
+            # fp8 chain: LayerNorm -> e4m3, GEGLU on the fp8 MFMA -> e4m3 hidden, FF2 on the fp8 MFMA (+ fp32 residual)
+            a8 = self._ln(x32, ln_pfx, rows, c, fp8=True)
+            h8 = self._buf("ffh8", (rows, 4 * c), U8)
+            ops.gemm(a8, W[ff_pfx + ".w18"], w_exp=W[ff_pfx + ".w18e"], bias=W[ff_pfx + ".b1"], out_f8=h8, geglu=True)
+            ops.gemm(h8, W[ff_pfx + ".w28"], w_exp=W[ff_pfx + ".w28e"], bias=W[ff_pfx + ".b2"], residual=residual,
+                     out_f32=out_f32, out_f16=out_f16)
+            return
         step = self._slice_rows(rows, c, unit)
         a_buf = self._buf("ln16", (step, c), F16)
         h_buf = self._buf("ffh", (step, 4 * c), F16)
-        W = self.W
         for r0 in range(0, rows, step):
             r1 = min(r0 + step, rows)
             a, hidden = a_buf[: r1 - r0], h_buf[: r1 - r0]
@@ -254,19 +285,26 @@ class SevaEngine:
         """ResBlock.forward, reference layers.py:120-139.  x1 (‖ x2) fp32 [n, hw, c]."""
         W, pfx, hw = self.W, spec.prefix, h * w
         cin, cout = spec.cin, spec.cout
-        a16 = self._buf("gn16", (n, hw, cin), F16)
+        f8_1, f8_2 = pfx + ".conv1.w8" in W, pfx + ".conv2.w8" in W  # fp8 mode: the conv consumes e4m3 activations
+        a16 = None if f8_1 else self._buf("gn16", (n, hw, cin), F16)
+        a8 = self._buf("gn8", (n, hw, cin), U8) if f8_1 else None
         # the 1x1 skip conv (cin != cout) consumes the raw input as f16: emitted by the same GroupNorm pass
         xs16 = self._buf("skip16", (n * hw, cin), F16) if cin != cout else None
         ops.groupnorm(x1, x2, W[pfx + ".in_layers.0.g"], W[pfx + ".in_layers.0.b"], a16, self.gn_ws,
                       eps=1e-5, silu=True, dense=dense, dense_w=W[pfx + ".dense.w"], dense_b=W[pfx + ".dense.b"],
-                      raw_f16=xs16)
+                      raw_f16=xs16, out_f8=a8)
         hmid = self._buf("res_mid", (n, hw, cout), F32)
         off = self.emb_off[pfx]
-        ops.conv3x3(a16.view(n, h, w, cin), W[pfx + ".conv1.w"], bias=W[pfx + ".conv1.b"],
-                    row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
-        b16 = self._buf("gn16", (n, hw, cout), F16)
+        if f8_1:
+            ops.conv3x3(a8.view(n, h, w, cin), W[pfx + ".conv1.w8"], w_exp=W[pfx + ".conv1.w8e"], bias=W[pfx + ".conv1.b"],
+                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
+        else:
+            ops.conv3x3(a16.view(n, h, w, cin), W[pfx + ".conv1.w"], bias=W[pfx + ".conv1.b"],
+                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
+        b16 = None if f8_2 else self._buf("gn16", (n, hw, cout), F16)
+        b8 = self._buf("gn8", (n, hw, cout), U8) if f8_2 else None
         ops.groupnorm(hmid, None, W[pfx + ".out_layers.0.g"], W[pfx + ".out_layers.0.b"], b16, self.gn_ws,
-                      eps=1e-5, silu=True)
+                      eps=1e-5, silu=True, out_f8=b8)
         if cin != cout:
             res = self._buf("skip32", (n * hw, cout), F32)
             ops.gemm(xs16, W[pfx + ".skip.w"], bias=W[pfx + ".skip.b"], out_f32=res)
@@ -274,8 +312,12 @@ class SevaEngine:
             assert x2 is None
             res = x1
         out = self._buf("out:" + pfx, (n, hw, cout), F32)
-        ops.conv3x3(b16.view(n, h, w, cout), W[pfx + ".conv2.w"], bias=W[pfx + ".conv2.b"],
-                    residual=res, out_f32=out)
+        if f8_2:
+            ops.conv3x3(b8.view(n, h, w, cout), W[pfx + ".conv2.w8"], w_exp=W[pfx + ".conv2.w8e"], bias=W[pfx + ".conv2.b"],
+                        residual=res, out_f32=out)
+        else:
+            ops.conv3x3(b16.view(n, h, w, cout), W[pfx + ".conv2.w"], bias=W[pfx + ".conv2.b"],
+                        residual=res, out_f32=out)
         return out
 
     def _self_attention(self, x32, ln_pfx, at_pfx, rows, c, heads, *, regime, n, hw, T, residual,
@@ -302,11 +344,15 @@ class SevaEngine:
                          row_add=None if row_add is None else row_add[f0:], rows_per_group=rpg, ld_row_add=ldra,
                          out_f32=out_f32[r0:r1])
             return
-        a = self._ln(x32, ln_pfx, rows, c)
         qkv = self._buf("qkv", (rows, 3 * c), F16)
         # softmax scale * log2(e) rides on the q third of the projection (fp32, before the single f16
         # rounding), so the attention kernel exponentiates its MFMA output directly
-        ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)
+        if at_pfx + ".qkv8" in W:  # fp8 mode: e4m3 LayerNorm output x e4m3 weights, f16 q/k/v out
+            a8 = self._ln(x32, ln_pfx, rows, c, fp8=True)
+            ops.gemm(a8, W[at_pfx + ".qkv8"], w_exp=W[at_pfx + ".qkv8e"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)
+        else:
+            a = self._ln(x32, ln_pfx, rows, c)
+            ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)
         att = self._buf("att", (rows, c), F16)
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         if regime == "frame":  # batch = frame, tokens = pixels

@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("n", c_int32), ("ih", c_int32), ("iw", c_int32), ("cin", c_int32),
         ("oh", c_int32), ("ow", c_int32), ("stride", c_int32), ("upsample", c_int32),
         ("col_scale", c_float), ("col_scale_n", c_int32), ("pad_br_only", c_int32),
+        ("w_exp", c_void_p), ("out_f8", c_void_p), ("ldo8", c_int64),
     ]
 
 
@@ -57,7 +58,7 @@ class GroupNormDesc(C.Structure):
         ("out_f16", c_void_p), ("workspace", c_void_p),
         ("n", c_int32), ("hw", c_int32), ("c1", c_int32), ("c2", c_int32),
         ("groups", c_int32), ("dense_c", c_int32), ("silu", c_int32), ("eps", c_float),
-        ("raw_f16", c_void_p),
+        ("raw_f16", c_void_p), ("out_f8", c_void_p),
     ]
 
 
@@ -67,9 +68,11 @@ SYMBOLS = {
     "seva_abi_version": (c_int, []),
     "seva_target_arch": (c_char_p, []),
     "seva_gemm_f16": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "seva_gemm_fp8": (c_int, [POINTER(GemmDesc), c_void_p]),
     "seva_attention_f16": (c_int, [POINTER(AttnDesc), c_void_p]),
     "seva_groupnorm_f16": (c_int, [POINTER(GroupNormDesc), c_void_p]),
     "seva_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "seva_layernorm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "seva_softmax_rows_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "seva_nchw_to_nhwc_f16": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "seva_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

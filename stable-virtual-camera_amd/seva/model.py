@@ -158,8 +158,15 @@ class Seva(nn.Module):
         if self._engine is None:
             from ._engine import SevaEngine
 
-            self._engine = SevaEngine(self)
+            self._engine = SevaEngine(self, getattr(self, "_precision", None))
         return self._engine
+
+    def set_precision(self, precision: str) -> "Seva":
+        """"f16" (default, the parity mode) or "fp8" (BASELINE config 5: e4m3 operands on the fp8 MFMA where the reduction
+        length allows; separate accuracy class).  Re-packs the weights on the next forward."""
+        self._precision = precision
+        self._engine = None
+        return self
 
     def forward(
         self,

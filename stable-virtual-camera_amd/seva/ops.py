@@ -16,6 +16,7 @@ from . import _native as nv
 from ._native import AttnDesc, GemmDesc, GroupNormDesc, check, ptr, require_cuda, stream_ptr
 
 F16, F32 = torch.float16, torch.float32
+U8 = torch.uint8  # e4m3 bytes travel as uint8 tensors (bit pattern of torch.float8_e4m3fn)
 
 
 def _lib():
@@ -36,11 +37,16 @@ def gemm(
     geglu: bool = False,
     col_scale: float = 1.0,
     col_scale_n: int = 0,
+    w_exp: torch.Tensor | None = None,
+    out_f8: torch.Tensor | None = None,
 ) -> None:
     """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16).
-    Output features < col_scale_n are multiplied by col_scale in fp32 (plain epilogue only)."""
+    Output features < col_scale_n are multiplied by col_scale in fp32 (plain epilogue only).
+    fp8 mode (seva_gemm_fp8): a, w are uint8 tensors of e4m3 bytes and w_exp [N] uint8 the weights' E8M0 scale bytes;
+    out_f8 (GEGLU epilogue only) receives the hidden activations as e4m3."""
     require_cuda(a, w)
-    assert a.dtype == F16 and w.dtype == F16 and a.dim() == 2 and w.dim() == 2
+    fp8 = w_exp is not None
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype == (U8 if fp8 else F16)
     M, K = a.shape
     N = w.shape[0]
     d = GemmDesc()
@@ -55,7 +61,14 @@ def gemm(
     d.rows_per_group, d.ld_row_add = rows_per_group, ld_row_add
     d.mode, d.epilogue = 0, 1 if geglu else 0
     d.col_scale, d.col_scale_n = col_scale, col_scale_n
-    check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(a.device)), "seva_gemm_f16")
+    if fp8:
+        assert w_exp.dtype == U8 and w_exp.numel() == N and (out_f8 is None or out_f8.dtype == U8)
+        d.w_exp, d.out_f8 = w_exp.data_ptr(), ptr(out_f8)
+        d.ldo8 = out_f8.stride(0) if out_f8 is not None else 0
+        check(_lib().seva_gemm_fp8(C.byref(d), stream_ptr(a.device)), "seva_gemm_fp8")
+    else:
+        assert out_f8 is None
+        check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(a.device)), "seva_gemm_f16")
 
 
 def conv3x3(
@@ -72,11 +85,14 @@ def conv3x3(
     out_f32: torch.Tensor | None = None,
     out_f16: torch.Tensor | None = None,
     pad_br_only: bool = False,
+    w_exp: torch.Tensor | None = None,
 ) -> None:
     """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16.
-    pad_br_only: zero padding at the bottom / right edge only (diffusers Downsample2D, pad (0,1,0,1))."""
+    pad_br_only: zero padding at the bottom / right edge only (diffusers Downsample2D, pad (0,1,0,1)).
+    fp8 mode (w_exp given): x and w are uint8 tensors of e4m3 bytes, cin % 128 == 0, no fused upsample."""
     require_cuda(x, w)
-    assert x.dtype == F16 and w.dtype == F16 and x.dim() == 4 and x.is_contiguous()
+    fp8 = w_exp is not None
+    assert x.dtype == w.dtype == (U8 if fp8 else F16) and x.dim() == 4 and x.is_contiguous()
     n, ih, iw, cin = x.shape
     eh, ew = (2 * ih, 2 * iw) if upsample else (ih, iw)
     ps = 1 if pad_br_only else 2
@@ -95,7 +111,12 @@ def conv3x3(
     d.n, d.ih, d.iw, d.cin, d.oh, d.ow = n, ih, iw, cin, oh, ow
     d.stride, d.upsample = stride, 1 if upsample else 0
     d.pad_br_only = 1 if pad_br_only else 0
-    check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(x.device)), "seva_gemm_f16(conv)")
+    if fp8:
+        assert w_exp.dtype == U8 and w_exp.numel() == w.shape[0]
+        d.w_exp = w_exp.data_ptr()
+        check(_lib().seva_gemm_fp8(C.byref(d), stream_ptr(x.device)), "seva_gemm_fp8(conv)")
+    else:
+        check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(x.device)), "seva_gemm_f16(conv)")
 
 
 def attention(
@@ -150,16 +171,20 @@ def groupnorm(
     dense_w: torch.Tensor | None = None,
     dense_b: torch.Tensor | None = None,
     raw_f16: torch.Tensor | None = None,
+    out_f8: torch.Tensor | None = None,
 ) -> None:
     """GroupNorm(+SiLU)(+Pluecker modulation) of cat(x1, x2) -> f16; x: [n, hw, c] f32.
-    raw_f16: optional second output, cat(x1, x2) merely cast to f16 (same pass)."""
-    require_cuda(x1, out_f16)
+    raw_f16: optional second output, cat(x1, x2) merely cast to f16 (same pass).
+    out_f8: optional e4m3 output (uint8 tensor, same layout); out_f16 may then be None."""
+    require_cuda(x1, out_f16 if out_f16 is not None else out_f8)
     n, hw, c1 = x1.shape
     c2 = x2.shape[2] if x2 is not None else 0
     d = GroupNormDesc()
     d.x1, d.x2, d.gamma, d.beta = x1.data_ptr(), ptr(x2), gamma.data_ptr(), beta.data_ptr()
     d.dense, d.dense_w, d.dense_b = ptr(dense), ptr(dense_w), ptr(dense_b)
-    d.out_f16, d.workspace = out_f16.data_ptr(), workspace.data_ptr()
+    d.out_f16, d.workspace = ptr(out_f16), workspace.data_ptr()
+    d.out_f8 = ptr(out_f8)
+    assert out_f8 is None or (out_f8.dtype == U8 and out_f8.is_contiguous() and out_f8.numel() == n * hw * (c1 + c2))
     d.n, d.hw, d.c1, d.c2, d.groups = n, hw, c1, c2, groups
     d.dense_c = dense.shape[-1] if dense is not None else 0
     d.silu, d.eps = 1 if silu else 0, eps
@@ -171,12 +196,39 @@ def groupnorm(
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_f16: torch.Tensor,
               eps: float = 1e-5) -> None:
+    """LayerNorm over the last dim; the output dtype selects the kernel: f16, or uint8 = e4m3 bytes (seva_layernorm_fp8)."""
     require_cuda(x, out_f16)
     c = x.shape[-1]
     rows = x.numel() // c
+    if out_f16.dtype == U8:
+        check(_lib().seva_layernorm_fp8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        out_f16.data_ptr(), rows, c, eps, stream_ptr(x.device)),
+              "seva_layernorm_fp8")
+        return
+    assert out_f16.dtype == F16
     check(_lib().seva_layernorm_f16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                     out_f16.data_ptr(), rows, c, eps, stream_ptr(x.device)),
           "seva_layernorm_f16")
+
+
+def quantize_weight_fp8(w: torch.Tensor):
+    """[N, K] weights -> (e4m3 bytes [N, K] uint8, E8M0 scale bytes [N] uint8): row n holds e4m3(w[n] * 2^-e[n]) with the
+    power-of-two scale 2^e[n] chosen so that max|row| lands in (224, 448] (the top binade of e4m3); the scale byte is
+    127 + e[n], what the block-scaled MFMA takes (seva_gemm_fp8).  Pack-time host utility (torch's own e4m3 cast)."""
+    w = w.float()
+    amax = w.abs().amax(dim=1).clamp_min(1e-30)
+    e = torch.ceil(torch.log2(amax / 448.0)).clamp(-126, 127)
+    q = (w * torch.exp2(-e)[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), (e + 127).to(torch.uint8).contiguous()
+
+
+def dequantize_weight_fp8(w8: torch.Tensor, w_exp: torch.Tensor) -> torch.Tensor:
+    return w8.view(torch.float8_e4m3fn).float() * torch.exp2(w_exp.float() - 127.0)[:, None]
+
+
+def to_fp8(x: torch.Tensor) -> torch.Tensor:
+    """float tensor -> e4m3 bytes (saturating), uint8 view (host utility for tests / one-off conversions)."""
+    return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
 
 
 def softmax_rows(x: torch.Tensor, out_f16: torch.Tensor, cols: int, scale: float) -> None:

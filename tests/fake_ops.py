@@ -7,10 +7,31 @@ import math
 import torch
 import torch.nn.functional as F
 
-F16, F32 = torch.float16, torch.float32
+F16, F32, U8 = torch.float16, torch.float32, torch.uint8
 
 
-def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu):
+# host-side e4m3 helpers of the real module (pure torch, no kernels)
+def to_fp8(x):
+    return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def _from_fp8(x8):
+    return x8.view(torch.float8_e4m3fn).float()
+
+
+def quantize_weight_fp8(w):
+    w = w.float()
+    amax = w.abs().amax(dim=1).clamp_min(1e-30)
+    e = torch.ceil(torch.log2(amax / 448.0)).clamp(-126, 127)
+    q = (w * torch.exp2(-e)[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), (e + 127).to(torch.uint8).contiguous()
+
+
+def dequantize_weight_fp8(w8, w_exp):
+    return _from_fp8(w8) * torch.exp2(w_exp.float() - 127.0)[:, None]
+
+
+def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu, out_f8=None):
     if geglu:
         if bias is not None:
             acc = acc + bias
@@ -30,26 +51,36 @@ def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, ou
         out_f32.view(M, -1)[:, : acc.shape[1]].copy_(acc)
     if out_f16 is not None:
         out_f16.view(M, -1)[:, : acc.shape[1]].copy_(acc.half())
+    if out_f8 is not None:
+        out_f8.view(M, -1)[:, : acc.shape[1]].copy_(to_fp8(acc))
 
 
 def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, residual=None,
-         out_f32=None, out_f16=None, geglu=False, col_scale=1.0, col_scale_n=0):
-    assert a.dtype == F16 and w.dtype == F16 and a.shape[1] % 64 == 0
+         out_f32=None, out_f16=None, geglu=False, col_scale=1.0, col_scale_n=0, w_exp=None, out_f8=None):
     M, N = a.shape[0], w.shape[0]
-    acc = a.float() @ w.float().T
+    if w_exp is not None:  # seva_gemm_fp8
+        assert a.dtype == U8 and w.dtype == U8 and a.shape[1] % 128 == 0 and N % 16 == 0
+        acc = _from_fp8(a) @ dequantize_weight_fp8(w, w_exp).T
+    else:
+        assert a.dtype == F16 and w.dtype == F16 and a.shape[1] % 64 == 0 and out_f8 is None
+        acc = a.float() @ w.float().T
     if col_scale_n:
         assert residual is None and row_add is None and not geglu
         if bias is not None:
             acc = acc + bias
             bias = None
         acc[:, :col_scale_n] *= col_scale
-    _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu)
+    _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu, out_f8)
 
 
 def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
-            ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False):
+            ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None):
     n, ih, iw, cin = x.shape
-    assert x.dtype == F16 and cin % 64 == 0 and w.shape[1] == 9 * cin
+    if w_exp is not None:  # seva_gemm_fp8, conv mode
+        assert x.dtype == U8 and w.dtype == U8 and cin % 128 == 0 and w.shape[1] == 9 * cin and not upsample
+        x, w = _from_fp8(x), dequantize_weight_fp8(w, w_exp)
+    else:
+        assert x.dtype == F16 and cin % 64 == 0 and w.shape[1] == 9 * cin
     xi = x.float().permute(0, 3, 1, 2)
     if upsample:
         xi = F.interpolate(xi, scale_factor=2, mode="nearest")
@@ -81,7 +112,7 @@ def groupnorm_workspace(n, device):
 
 
 def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, silu=False,
-              dense=None, dense_w=None, dense_b=None, raw_f16=None):
+              dense=None, dense_w=None, dense_b=None, raw_f16=None, out_f8=None):
     x = torch.cat([x1, x2], -1) if x2 is not None else x1
     if raw_f16 is not None:
         raw_f16.view(x.shape).copy_(x.half())
@@ -92,12 +123,16 @@ def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, s
     if dense is not None:
         d = dense @ dense_w.T + dense_b
         y = y * (1 + d[..., :C]) + d[..., C:]
-    out_f16.copy_(y.half())
+    if out_f16 is not None:
+        out_f16.copy_(y.half())
+    if out_f8 is not None:
+        out_f8.copy_(to_fp8(y))
 
 
 def layernorm(x, gamma, beta, out_f16, eps=1e-5):
     c = x.shape[-1]
-    out_f16.view(-1, c).copy_(F.layer_norm(x.reshape(-1, c), (c,), gamma, beta, eps).half())
+    y = F.layer_norm(x.reshape(-1, c), (c,), gamma, beta, eps)
+    out_f16.view(-1, c).copy_(to_fp8(y) if out_f16.dtype == U8 else y.half())
 
 
 def softmax_rows(x, out_f16, cols, scale):

@@ -65,7 +65,7 @@ def test_weight_packing_layouts():
     assert pack_conv3x3(torch.randn(8, 11, 3, 3), 64).shape == (8, 576)
 
 
-def _cpu_engine(tag="tiny"):
+def _cpu_engine(tag="tiny", precision=None):
     """Engine on CPU with the HIP ops replaced by fake_ops (test-only construction)."""
     from seva import _engine, synthetic as synth
     from seva.model import Seva, SevaParams
@@ -77,7 +77,7 @@ def _cpu_engine(tag="tiny"):
     orig = _engine.SevaEngine.__dict__["_resolve_device"]
     _engine.SevaEngine._resolve_device = staticmethod(lambda m: torch.device("cpu"))  # test seam
     try:
-        eng = _engine.SevaEngine(net)
+        eng = _engine.SevaEngine(net, precision)
     finally:
         _engine.SevaEngine._resolve_device = orig
     return eng, sd
@@ -367,3 +367,30 @@ def test_vae_loader_is_strict_and_maps_legacy_attention_names(tmp_path, monkeypa
     safetensors.torch.save_file(extra, path)
     with pytest.raises(RuntimeError, match="unexpected"):
         A.AutoEncoder(chunk_size=1)
+
+
+
+def test_fp8_engine_orchestration(patched):
+    """BASELINE config 5 wiring on the CPU (emulated kernels): in fp8 mode every eligible layer (C % 128 == 0: QKV, GEGLU,
+    FF2, ResBlock convs) gets e4m3 weights + scale bytes and the engine routes e4m3 activations to them; the result stays
+    close to the fp32 oracle at e4m3 accuracy (a few per cent -- a separate accuracy class, never the parity mode)."""
+    from oracle import seva_ref as O
+    eng, sd = _cpu_engine(precision="fp8")
+    assert eng.fp8
+    q = [k for k in eng.W if k.endswith("8e")]
+    assert any(".qkv8e" in k for k in q) and any(".w18e" in k for k in q) and any(".w28e" in k for k in q)
+    assert any(".conv1.w8e" in k for k in q) and any(".conv2.w8e" in k for k in q)
+    # the C = 64 level has no 128-deep reduction: stays f16
+    assert not any(k.startswith("input_blocks.1.") and k.endswith("8e") for k in q)
+    T, h, w = 2, 8, 8
+    g = torch.Generator().manual_seed(3)
+    n = 2 * T
+    x, t = torch.randn(n, 11, h, w, generator=g), torch.randint(0, 1000, (n,), generator=g)
+    y, dense = torch.randn(n, 1, 1024, generator=g), torch.randn(n, 6, h, w, generator=g)
+    out = eng.forward(x, None, t, y, dense, T)
+    ref = O.seva_forward(sd, x, t, y, dense, T)
+    err = rel_l2(out, ref)
+    print(f"fp8 engine (emulated kernels) vs fp32 oracle: rel-L2 {err:.3e}")
+    assert 1e-3 < err < 0.15
+    f16_eng, _ = _cpu_engine()
+    assert not f16_eng.fp8 and not any(k.endswith("8e") for k in f16_eng.W)

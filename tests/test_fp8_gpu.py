@@ -1,0 +1,183 @@
+"""fp8 (OCP e4m3) operators of BASELINE config 5 through the C-ABI: `seva_gemm_fp8` (plain, GEGLU, conv3x3) on the
+block-scaled MFMA, and the e4m3-emitting producers (`seva_layernorm_fp8`, `seva_groupnorm_f16(out_f8=...)`).
+
+GEMM / conv are checked BIT-EXACTLY on integer data: small integers are exact in e4m3, the per-channel weight scale
+is a power of two carried by the MFMA's E8M0 block scale, and fp32 accumulation of such products is exact -- any
+operand-map, k-permutation or scale-routing mistake shows as a mismatch.  Quantising producers are checked against
+torch's own e4m3 cast of an fp32 reference (equal up to one e4m3 ulp at rounding ties of the fp32 arithmetic)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from conftest import rel_l2
+
+U8 = torch.uint8
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from seva import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+def _ints(shape, lo, hi, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float().to(dev)
+
+
+def _f8(x):
+    from seva import ops
+    return ops.to_fp8(x)
+
+
+def _wq(w_int, dev, seed):
+    """integer weights + random power-of-two row scales -> (e4m3 bytes, scale bytes, de-quantised fp32 weights)"""
+    g = torch.Generator().manual_seed(seed)
+    e = torch.randint(-3, 4, (w_int.shape[0],), generator=g).to(dev)
+    return _f8(w_int), (e + 127).to(U8), w_int * torch.exp2(e.float())[:, None]
+
+
+@pytest.mark.parametrize("chunks", [-1, 1])
+@pytest.mark.parametrize("M,N,K", [(300, 640, 640), (1000, 1920, 640), (257, 1280, 256), (2049, 320, 1280),
+                                   (64, 640, 128), (515, 160, 384)])
+def test_gemm_fp8_exact(dev, M, N, K, chunks, knobs):
+    from seva import ops
+    knobs(gemm_chunks=chunks)
+    a = _ints((M, K), -4, 4, dev, 1)
+    w8, wexp, wf = _wq(_ints((N, K), -3, 3, dev, 2), dev, 3)
+    bias = _ints((N,), -5, 5, dev, 4)
+    res = _ints((M, N), -9, 9, dev, 5)
+    rpg = 100
+    radd = _ints(((M + rpg - 1) // rpg, N), -3, 3, dev, 6)
+    ref = a @ wf.T + bias + res + radd.repeat_interleave(rpg, 0)[:M]
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    o16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    ops.gemm(_f8(a), w8, w_exp=wexp, bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o32, out_f16=o16)
+    torch.cuda.synchronize()
+    assert torch.equal(o32, ref), f"max diff {(o32 - ref).abs().max()}"
+    assert torch.equal(o16.float(), ref.half().float())
+    # f16-only output: the ASYNC schedule (scale bytes ride in through the LDS slot), with the q-column scale
+    o16b = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    csn = N // 4 // 4 * 4
+    for _ in range(2):
+        ops.gemm(_f8(a), w8, w_exp=wexp, bias=bias, out_f16=o16b, col_scale=0.5, col_scale_n=csn)
+    ref2 = a @ wf.T + bias
+    ref2[:, :csn] *= 0.5
+    assert torch.equal(o16b.float(), ref2.half().float())
+
+
+@pytest.mark.parametrize("M,C,K", [(300, 640, 640), (1000, 320, 1280), (131, 1280, 128)])
+def test_geglu_fp8(dev, M, C, K, knobs):
+    """GEGLU epilogue on the fp8 kernel; the e4m3 hidden output equals torch's e4m3 cast of the fp32 output of the same launch."""
+    from seva import ops
+    from seva._engine import interleave_geglu
+    knobs(gemm_chunks=1)
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(8 * C, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(8 * C, generator=g).to(dev)
+    wi, bi = interleave_geglu(w, b)
+    w8, wexp = ops.quantize_weight_fp8(wi)
+    a8 = _f8(a)
+    o32 = torch.full((M, 4 * C), float("nan"), device=dev)
+    o8 = torch.zeros((M, 4 * C), device=dev, dtype=U8)
+    ops.gemm(a8, w8, w_exp=wexp, bias=bi, out_f32=o32, out_f8=o8, geglu=True)
+    # reference on the operands the kernel sees (de-quantised), original row order
+    aq = a8.view(torch.float8_e4m3fn).float()
+    wq_i = ops.dequantize_weight_fp8(w8, wexp)
+    y = aq @ wq_i.T + bi
+    yv = y.view(M, -1, 2, 32)
+    ref = (yv[:, :, 0] * F.gelu(yv[:, :, 1])).reshape(M, 4 * C)
+    assert torch.isfinite(o32).all() and rel_l2(o32, ref) < 2e-5
+    assert torch.equal(o8, _f8(o32))
+    o8b = torch.zeros_like(o8)  # e4m3-only output: ASYNC schedule
+    ops.gemm(a8, w8, w_exp=wexp, bias=bi, out_f8=o8b, geglu=True)
+    assert torch.equal(o8b, o8)
+
+
+@pytest.mark.parametrize("n,ih,iw,cin,cout,stride", [(2, 9, 7, 128, 64, 1), (1, 12, 10, 256, 96, 2), (3, 8, 8, 640, 160, 1),
+                                                     (42, 9, 9, 128, 320, 1)])
+def test_conv3x3_fp8_exact(dev, n, ih, iw, cin, cout, stride):
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    x = _ints((n, cin, ih, iw), -3, 3, dev, 1)
+    w = _ints((cout, cin, 3, 3), -2, 2, dev, 2)
+    g = torch.Generator().manual_seed(3)
+    e = torch.randint(-2, 3, (cout,), generator=g).to(dev)
+    wf = w * torch.exp2(e.float())[:, None, None, None]
+    bias = _ints((cout,), -4, 4, dev, 3)
+    ref = F.conv2d(x, wf, bias, stride=stride, padding=1)
+    oh, ow = ref.shape[-2:]
+    temb = _ints((n, cout), -2, 2, dev, 4)
+    res = _ints((n, oh * ow, cout), -5, 5, dev, 5)
+    ref = ref + temb[:, :, None, None] + res.view(n, oh, ow, cout).permute(0, 3, 1, 2)
+    w8 = _f8(pack_conv3x3(w).float())
+    out = torch.full((n, oh * ow, cout), float("nan"), device=dev)
+    ops.conv3x3(_f8(x.permute(0, 2, 3, 1).contiguous()), w8, w_exp=(e + 127).to(U8), stride=stride, bias=bias,
+                row_add=temb, rows_per_group=oh * ow, residual=res, out_f32=out)
+    got = out.view(n, oh, ow, cout).permute(0, 3, 1, 2)
+    assert torch.equal(got, ref), f"max diff {(got - ref).abs().max()}"
+
+
+def _close_fp8(got_u8, ref_f32):
+    """e4m3 bytes vs an fp32 reference: equal to torch's cast except where fp32 arithmetic differences cross a rounding tie."""
+    got = got_u8.view(torch.float8_e4m3fn).float()
+    want = _f8(ref_f32).view(torch.float8_e4m3fn).float()
+    same = (got == want).float().mean().item()
+    ulp = torch.maximum(ref_f32.abs() * 2.0 ** -3, torch.tensor(2.0 ** -9, device=ref_f32.device))
+    assert same > 0.995 and bool(((got - ref_f32).abs() <= ulp).all()), same
+    return same
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 640), (70000, 320), (333, 1280)])
+def test_layernorm_fp8(dev, rows, c):
+    from seva import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(rows, c, generator=g) * 3 + 0.5).to(dev)
+    gm, bt = (1 + 0.1 * torch.randn(c, generator=g)).to(dev), (0.1 * torch.randn(c, generator=g)).to(dev)
+    out = torch.zeros((rows, c), device=dev, dtype=U8)
+    ops.layernorm(x, gm, bt, out)
+    ref = F.layer_norm(x, (c,), gm, bt, 1e-5)
+    print(f"layernorm fp8 [{rows},{c}]: {_close_fp8(out, ref) * 100:.2f} % identical to torch's e4m3 cast")
+
+
+def test_groupnorm_fp8_output(dev):
+    from seva import ops
+    n, hw, c = 3, 100, 256
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(n, hw, c, generator=g) * 2 + 1).to(dev)
+    gm, bt = (1 + 0.1 * torch.randn(c, generator=g)).to(dev), (0.1 * torch.randn(c, generator=g)).to(dev)
+    ws = ops.groupnorm_workspace(n, dev)
+    o16 = torch.zeros((n, hw, c), device=dev, dtype=torch.float16)
+    o8 = torch.zeros((n, hw, c), device=dev, dtype=U8)
+    ops.groupnorm(x, None, gm, bt, o16, ws, silu=True, out_f8=o8)
+    ref = F.silu(F.group_norm(x.permute(0, 2, 1), 32, gm, bt, 1e-5)).permute(0, 2, 1)
+    _close_fp8(o8, ref)
+    o8b = torch.zeros_like(o8)
+    ops.groupnorm(x, None, gm, bt, None, ws, silu=True, out_f8=o8b)  # e4m3 only
+    assert torch.equal(o8, o8b) and rel_l2(o16, ref) < 1e-3
+
+
+def test_fp8_network_accuracy_is_reported(dev):
+    """BASELINE config 5 at network level: the 1.3B forward of config 1 in fp8 mode against the REFERENCE golden.  e4m3
+    carries 3 mantissa bits, so this mode is far outside the 1e-3 parity tolerance by construction; the number is
+    REPORTED (and bounded loosely so that a wiring bug -- O(1) error -- still fails).  f16 stays the parity mode."""
+    from conftest import load_golden
+    from test_model_gpu import _build
+    from seva.model import SGMWrapper
+    net, _ = _build("full", dev)
+    g = load_golden("g4_full_forward")
+    T = int(g["T"])
+    c = {k: g[k].to(dev) for k in ("crossattn", "concat", "dense_vector")}
+    y16 = SGMWrapper(net)(g["x"].to(dev), g["t"].to(dev), c, num_frames=T).cpu()
+    net.set_precision("fp8")
+    y8 = SGMWrapper(net)(g["x"].to(dev), g["t"].to(dev), c, num_frames=T).cpu()
+    e16, e8 = rel_l2(y16, g["y"]), rel_l2(y8, g["y"])
+    nq = sum(1 for k in net.engine().W if k.endswith("8e"))
+    print(f"\n1.3B forward (config 1) vs reference: f16 mode rel-L2 {e16:.3e}; fp8 mode rel-L2 {e8:.3e} ({nq} e4m3 weight tensors)")
+    assert e16 < 1e-3 and 1e-3 < e8 < 0.2 and nq > 100

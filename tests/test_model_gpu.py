@@ -217,7 +217,7 @@ def test_tiny_sampler_loop_vs_golden(dev, tiny):
     y = _sampler_run(net, dev, int(g["T"]), int(g["hw"]), int(g["steps"]), list(g["eps"]))
     err = rel_l2(y.cpu(), g["y"])
     print(f"tiny 4-step sampler loop vs reference golden: rel-L2 {err:.3e}")
-    assert err < 2e-3  # four chained network calls
+    assert err < NET_TOL  # four chained network calls, still inside the per-latent tolerance (measured 6.6e-4)
 
 
 def test_guiders_and_denoiser_vs_golden(dev, tiny):
@@ -278,8 +278,9 @@ def test_full_sampler_loop_vs_golden(dev, full):
     g = load_golden("g7_loop_full")
     y = _sampler_run(net, dev, int(g["T"]), int(g["hw"]), int(g["steps"]), list(g["eps"]))
     err = rel_l2(y.cpu(), g["y"])
-    print(f"1.3B 4-step sampler loop (config 1) vs reference golden: rel-L2 {err:.3e}")
-    assert err < 2e-3
+    per = [rel_l2(y[i].cpu(), g["y"][i]) for i in range(y.shape[0])]
+    print(f"1.3B 4-step sampler loop (config 1) vs reference golden: rel-L2 {err:.3e}; per latent max {max(per):.3e}")
+    assert err < NET_TOL and max(per) < NET_TOL  # measured 6.1e-4
 
 
 # ------------------------------------------------------------------ VAE decoder (parity UNPINNED)
