@@ -247,6 +247,26 @@ int seva_cond_concat_f32(const float* plucker, const uint8_t* mask, float* c_con
                          int32_t views, int32_t h, int32_t w, seva_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CLIP ViT-H-14 image conditioner (seva/modules/conditioner.py:7-39).  Its GEMMs / LayerNorms are
+ * seva_gemm_f16 / seva_layernorm_*; these three entry points are what those cannot express.
+ */
+/* LayerNorm with fp32 output (CLIP's ln_pre: the result IS the residual stream).  No overlap of x and out. */
+int seva_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out_f32, int64_t rows,
+                       int32_t c, float eps, seva_stream_t stream);
+/* conditioner.py:24-34: kornia.geometry.resize(x, (out,out), bicubic, align_corners=True, antialias) -> (x+1)/2 ->
+ * normalize(mean, std); x: [n][3][H][W] fp32 in [-1,1].  The result is written as the f16 patch matrix of the
+ * patch x patch / stride-patch embedding conv: row = image * (out/patch)^2 + py * (out/patch) + px, column =
+ * (c * patch + ky) * patch + kx (= conv weight .reshape(width, 3*patch*patch)); columns beyond 3*patch^2 are untouched. */
+int seva_clip_preprocess_f16(const float* x, void* patches_f16, int32_t n, int32_t H, int32_t W, int32_t out_size,
+                             int32_t patch, int32_t ld_patches, const float* mean, const float* std,
+                             int32_t antialias, seva_stream_t stream);
+/* softmax(q k^T * scale) v for short sequences and any even head dim <= 128 (ViT-H-14: L = 257, d = 80), f16 in/out,
+ * fp32 math.  Element (b, token l, head h, d) of q at q + b*q_sb + l*q_sl + h*head_dim + d; k, v share strides. */
+int seva_attention_small_f16(const void* q, const void* k, const void* v, void* out, int64_t q_sb, int64_t q_sl,
+                             int64_t k_sb, int64_t k_sl, int64_t o_sb, int64_t o_sl, int32_t batch, int32_t heads,
+                             int32_t L, int32_t head_dim, float scale, seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Benchmark / debugging knobs.  The library reads its SEVA_* environment variables ONCE, when it is loaded (nothing
  * on the launch path calls getenv); a host changes a knob at run time with seva_set_knob (tests, tools).  Names:
  * gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat, attn_dbg, attn_no_tr, attn_two,

@@ -259,12 +259,13 @@ __device__ __forceinline__ float group16_sum(float v) {
 // contiguous bytes per row and a lane keeps C/64 16-byte loads in flight.
 // LN_ROWS rows are walked by one 16-lane group: gamma / beta stay in registers, the next row is prefetched.  4 for big
 // tensors (ds1 93 -> 79 us); 1 when that would leave fewer workgroups than ~4 per CU.
-template <int NV, int LN_ROWS, bool F8 = false>
+// OUT: 0 = f16, 1 = e4m3 bytes, 2 = fp32 (a LayerNorm whose result IS the residual stream: CLIP's ln_pre)
+template <int NV, int LN_ROWS, int OUT = 0>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         half_t* __restrict__ out, int64_t rows,
-                                                        int c, float eps) {  // F8: `out` is an e4m3 byte buffer
+                                                        int c, float eps) {  // OUT 1 / 2: `out` is an e4m3 / fp32 buffer
   const int sub = threadIdx.x & 15;
   const int cq = c >> 2;
   // group g of the block owns rows base + g, base + g + 16, ... (consecutive groups touch consecutive rows per pass)
@@ -318,11 +319,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (i < cq) {
           const f32x4 g4 = HOIST ? gm[HOIST ? k : 0] : *(const f32x4*)(gamma + i * 4);
           const f32x4 b4 = HOIST ? bt[HOIST ? k : 0] : *(const f32x4*)(beta + i * 4);
-          if constexpr (F8) {
+          if constexpr (OUT != 0) {
             float y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = (v[k][r] - mean) * rstd * g4[r] + b4[r];
-            *(int*)((uint8_t*)out + row * c + i * 4) = pack_fp8x4(y[0], y[1], y[2], y[3]);
+            if constexpr (OUT == 1) *(int*)((uint8_t*)out + row * c + i * 4) = pack_fp8x4(y[0], y[1], y[2], y[3]);
+            else *(f32x4*)((float*)out + row * c + i * 4) = f32x4{y[0], y[1], y[2], y[3]};
           } else {
             half4_t h;
 #pragma unroll
@@ -425,14 +427,14 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
 }
 
 namespace {
-template <bool F8>
+template <int OUT>
 int layernorm_entry(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int32_t c, float eps,
                     seva_stream_t stream) {
   SEVA_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
   SEVA_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && c <= 16 * 4 * LN_MAXV,
                "layernorm: rows=%lld c=%d unsupported", (long long)rows, c);
   hipStream_t s = (hipStream_t)stream;
-  SevaProfScope prof(3, (double)rows * c * (F8 ? 5.0 : 6.0), s);
+  SevaProfScope prof(3, (double)rows * c * (OUT == 1 ? 5.0 : OUT == 2 ? 8.0 : 6.0), s);
   const int lr = rows >= 64 * 1024 ? 4 : 1;
   const int64_t blocks = (rows + 16 * lr - 1) / (16 * lr);
   SEVA_REQUIRE(blocks <= 0x7fffffff, "layernorm: too many rows");
@@ -440,10 +442,10 @@ int layernorm_entry(const float* x, const float* gamma, const float* beta, void*
 #define SEVA_LN_LAUNCH(NV)                                                                                  \
   do {                                                                                                      \
     if (lr == 4)                                                                                            \
-      hipLaunchKernelGGL((layernorm_kernel<NV, 4, F8>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
+      hipLaunchKernelGGL((layernorm_kernel<NV, 4, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
                          beta, (half_t*)out, rows, c, eps);                                                 \
     else                                                                                                    \
-      hipLaunchKernelGGL((layernorm_kernel<NV, 1, F8>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
+      hipLaunchKernelGGL((layernorm_kernel<NV, 1, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
                          beta, (half_t*)out, rows, c, eps);                                                 \
   } while (0)
   if (nv <= 2) SEVA_LN_LAUNCH(2);
@@ -458,14 +460,21 @@ int layernorm_entry(const float* x, const float* gamma, const float* beta, void*
 extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const float* beta,
                                   void* out_f16, int64_t rows, int32_t c, float eps,
                                   seva_stream_t stream) {
-  return layernorm_entry<false>(x, gamma, beta, out_f16, rows, c, eps, stream);
+  return layernorm_entry<0>(x, gamma, beta, out_f16, rows, c, eps, stream);
 }
 
 // same normalisation, output as OCP e4m3 bytes (saturating): A operand of seva_gemm_fp8
 extern "C" int seva_layernorm_fp8(const float* x, const float* gamma, const float* beta,
                                   void* out_f8, int64_t rows, int32_t c, float eps,
                                   seva_stream_t stream) {
-  return layernorm_entry<true>(x, gamma, beta, out_f8, rows, c, eps, stream);
+  return layernorm_entry<1>(x, gamma, beta, out_f8, rows, c, eps, stream);
+}
+
+// fp32 output (input and output must not overlap)
+extern "C" int seva_layernorm_f32(const float* x, const float* gamma, const float* beta,
+                                  float* out_f32, int64_t rows, int32_t c, float eps,
+                                  seva_stream_t stream) {
+  return layernorm_entry<2>(x, gamma, beta, out_f32, rows, c, eps, stream);
 }
 
 extern "C" int seva_softmax_rows_f16(const float* x, int64_t ldx, void* out_f16, int64_t ldo,

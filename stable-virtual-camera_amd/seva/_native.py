@@ -73,6 +73,11 @@ SYMBOLS = {
     "seva_groupnorm_f16": (c_int, [POINTER(GroupNormDesc), c_void_p]),
     "seva_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "seva_layernorm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "seva_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "seva_clip_preprocess_f16": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p, c_void_p, c_int32, c_void_p]),
+    "seva_attention_small_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                         c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "seva_softmax_rows_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "seva_nchw_to_nhwc_f16": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "seva_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

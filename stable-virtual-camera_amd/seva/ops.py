@@ -200,6 +200,12 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_f16:
     require_cuda(x, out_f16)
     c = x.shape[-1]
     rows = x.numel() // c
+    if out_f16.dtype == F32:
+        assert out_f16.data_ptr() != x.data_ptr()
+        check(_lib().seva_layernorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        out_f16.data_ptr(), rows, c, eps, stream_ptr(x.device)),
+              "seva_layernorm_f32")
+        return
     if out_f16.dtype == U8:
         check(_lib().seva_layernorm_fp8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         out_f16.data_ptr(), rows, c, eps, stream_ptr(x.device)),
@@ -229,6 +235,34 @@ def dequantize_weight_fp8(w8: torch.Tensor, w_exp: torch.Tensor) -> torch.Tensor
 def to_fp8(x: torch.Tensor) -> torch.Tensor:
     """float tensor -> e4m3 bytes (saturating), uint8 view (host utility for tests / one-off conversions)."""
     return x.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def clip_preprocess(x: torch.Tensor, patches_f16: torch.Tensor, mean, std, *, out_size: int = 224, patch: int = 14,
+                    antialias: bool = True) -> None:
+    """kornia-style resize + CLIP normalisation, emitted as the patch matrix of the patch-embedding GEMM
+    (seva_clip_preprocess_f16).  x: [n,3,H,W] f32 in [-1,1]; patches_f16: [n*(out/patch)^2, ld >= 3*patch^2] f16."""
+    require_cuda(x, patches_f16)
+    assert x.dtype == F32 and x.is_contiguous() and x.dim() == 4 and x.shape[1] == 3 and patches_f16.dtype == F16
+    n, _, H, W = x.shape
+    g = out_size // patch
+    assert patches_f16.shape[0] == n * g * g and patches_f16.stride(1) == 1
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    check(_lib().seva_clip_preprocess_f16(x.data_ptr(), patches_f16.data_ptr(), n, H, W, out_size, patch,
+                                          patches_f16.stride(0), C.cast(m, C.c_void_p), C.cast(sd, C.c_void_p),
+                                          1 if antialias else 0, stream_ptr(x.device)), "seva_clip_preprocess_f16")
+
+
+def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batch: int, heads: int,
+                    L: int, head_dim: int, q_strides: tuple[int, int], k_strides: tuple[int, int],
+                    o_strides: tuple[int, int], scale: float) -> None:
+    """softmax(q k^T * scale) v, short sequences, any even head dim <= 128 (seva_attention_small_f16); strides are
+    (batch, token) in elements, head h at column h * head_dim."""
+    require_cuda(q, k, v, out)
+    assert q.dtype == k.dtype == v.dtype == out.dtype == F16
+    check(_lib().seva_attention_small_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q_strides[0],
+                                          q_strides[1], k_strides[0], k_strides[1], o_strides[0], o_strides[1], batch,
+                                          heads, L, head_dim, scale, stream_ptr(q.device)), "seva_attention_small_f16")
 
 
 def softmax_rows(x: torch.Tensor, out_f16: torch.Tensor, cols: int, scale: float) -> None:

@@ -132,7 +132,34 @@ def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, s
 def layernorm(x, gamma, beta, out_f16, eps=1e-5):
     c = x.shape[-1]
     y = F.layer_norm(x.reshape(-1, c), (c,), gamma, beta, eps)
-    out_f16.view(-1, c).copy_(to_fp8(y) if out_f16.dtype == U8 else y.half())
+    out_f16.view(-1, c).copy_(to_fp8(y) if out_f16.dtype == U8 else (y if out_f16.dtype == F32 else y.half()))
+
+
+def clip_preprocess(x, patches_f16, mean, std, *, out_size=224, patch=14, antialias=True):
+    """emulates seva_clip_preprocess_f16 with torch ops (same published algorithm as oracle/clip_ref.py:preprocess)"""
+    n, c, H, W = x.shape
+    fy, fx = H / out_size, W / out_size
+    if antialias and max(fy, fx) > 1.0:
+        sy, sx = max((fy - 1.0) / 2.0, 0.001), max((fx - 1.0) / 2.0, 0.001)
+        ky, kx = int(max(4.0 * sy, 3)), int(max(4.0 * sx, 3))
+        ky, kx = ky + (ky % 2 == 0), kx + (kx % 2 == 0)
+        ty, tx = torch.arange(ky, dtype=F32) - ky // 2, torch.arange(kx, dtype=F32) - kx // 2
+        gy, gx = torch.exp(-ty * ty / (2 * sy * sy)), torch.exp(-tx * tx / (2 * sx * sx))
+        k2 = ((gy / gy.sum())[:, None] * (gx / gx.sum())[None, :])[None, None].repeat(c, 1, 1, 1)
+        x = F.conv2d(F.pad(x, (kx // 2, kx // 2, ky // 2, ky // 2), mode="reflect"), k2, groups=c)
+    x = F.interpolate(x, size=(out_size, out_size), mode="bicubic", align_corners=True)
+    x = ((x + 1.0) / 2.0 - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
+    g = out_size // patch
+    pm = x.view(n, c, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5).reshape(n * g * g, c * patch * patch)
+    patches_f16[:, : c * patch * patch].copy_(pm.half())
+
+
+def attention_small(q, k, v, out, *, batch, heads, L, head_dim, q_strides, k_strides, o_strides, scale):
+    def view(t, st):
+        return torch.as_strided(t, (batch, L, heads, head_dim), (st[0], st[1], head_dim, 1), t.storage_offset())
+    qv, kv, vv = view(q, q_strides).float(), view(k, k_strides).float(), view(v, k_strides).float()
+    att = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qv, kv) * scale, -1)
+    view(out, o_strides).copy_(torch.einsum("bhqk,bkhd->bqhd", att, vv).half())
 
 
 def softmax_rows(x, out_f16, cols, scale):

@@ -394,3 +394,43 @@ def test_fp8_engine_orchestration(patched):
     assert 1e-3 < err < 0.15
     f16_eng, _ = _cpu_engine()
     assert not f16_eng.fp8 and not any(k.endswith("8e") for k in f16_eng.W)
+
+
+def test_clip_engine_orchestration_vs_restatement(monkeypatch):
+    """CLIP conditioner host logic on the CPU (emulated kernels): weight packing incl. the GELU-through-GEGLU packing, the
+    patch-embedding GEMM with the positional embedding as residual, token plumbing, pooling; strict open_clip loading."""
+    from oracle import clip_ref as CR
+    from seva import _clip_engine, synthetic as synth
+    from seva.modules import conditioner as Cd
+    monkeypatch.setattr(_clip_engine, "ops", fake_ops)
+    monkeypatch.setattr(_clip_engine, "require_cuda", lambda *a: None)
+    monkeypatch.setattr(_clip_engine.ClipEngine, "_resolve_device", staticmethod(lambda w: torch.device("cpu")))
+    monkeypatch.delenv("SEVA_CLIP_PATH", raising=False)
+    monkeypatch.delenv("SEVA_CLIP_RANDOM_INIT", raising=False)
+    with pytest.raises(RuntimeError, match="no weights"):
+        Cd.CLIPConditioner()
+    p = Cd.ViTParams(width=320, layers=2, embed_dim=64)
+    cond = Cd.CLIPConditioner(p, random_init=True)
+    shapes = CR.vit_shapes(320, 2, 14, 224, 1280, 64)
+    assert {k: tuple(v.shape) for k, v in cond.module.state_dict().items()} == shapes
+    sd = synth.synth_state_dict(shapes, 5)
+    g = torch.Generator().manual_seed(1)
+    sd["visual.class_embedding"] = 0.02 * torch.randn(320, generator=g)
+    sd["visual.positional_embedding"] = 0.02 * torch.randn(257, 320, generator=g)
+    sd["visual.proj"] = torch.randn(320, 64, generator=g) * 320 ** -0.5
+    for k in shapes:
+        if k.endswith("in_proj_weight"):
+            sd[k] = torch.randn(shapes[k], generator=g) * 320 ** -0.5
+    # an open_clip CLIP checkpoint also carries the text tower: dropped knowingly; a missing vision key is an error
+    full = dict(sd, **{"logit_scale": torch.zeros(()), "token_embedding.weight": torch.zeros(4, 4)})
+    Cd.load_open_clip(cond.module, full)
+    broken = {k: v for k, v in full.items() if k != "visual.ln_post.bias"}
+    with pytest.raises(RuntimeError, match="missing"):
+        Cd.load_open_clip(cond.module, broken)
+    x = torch.rand(2, 3, 300, 260, generator=g) * 2 - 1
+    got = cond(x)
+    ref = CR.clip_conditioner(sd, x, heads=p.heads)
+    err = rel_l2(got, ref)
+    print(f"CLIP engine (emulated kernels) vs restatement: rel-L2 {err:.3e}")
+    assert got.shape == (2, 64) and err < 2e-3
+    assert rel_l2(cond.preprocess(x), CR.preprocess(x)) < 1e-3
