@@ -93,6 +93,27 @@ int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 int seva_gemm_fp8(const seva_gemm_desc* d, seva_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused GEGLU feed-forward (FeedForward of seva/modules/transformer.py:18-34) for narrow levels, C in {64,128,256,320}:
+ *   out[m][:] = W2 . (v * gelu_erf(g)) + b2 (+ residual[m][:]),  [v ; g] = W1 . a[m][:] + b1
+ * a: f16 [M][lda]; w1: f16 [8C][C] and b1: [8C] in the interleaved GEGLU layout of seva_gemm_f16 (groups of 64 rows =
+ * [32 value | 32 gate]); w2: f16 [C][4C]; b2: [C].  The 4C-wide hidden activations stay in registers (rounded to f16
+ * once, as the two-kernel form rounds the stored tensor); fp32 accumulation.
+ */
+typedef struct seva_ff_desc {
+  const void* a;
+  const void* w1;
+  const float* b1;
+  const void* w2;
+  const float* b2;
+  const float* residual; /* [M][ldr] or NULL */
+  float* out_f32;        /* [M][ldo32] or NULL */
+  void* out_f16;         /* [M][ldo16] or NULL */
+  int64_t M, lda, ldr, ldo32, ldo16;
+  int32_t C;
+} seva_ff_desc;
+int seva_ff_fused_f16(const seva_ff_desc* d, seva_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Scaled-dot-product attention, head dim 64, no mask, fp16 in/out, fp32 softmax.
  * Replaces F.scaled_dot_product_attention under sdpa_kernel(FLASH_ATTENTION)
  * (seva/modules/transformer.py:66-72) for the three regimes of SURVEY.md §2.1: per-frame,

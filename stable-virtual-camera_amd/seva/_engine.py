@@ -100,6 +100,7 @@ class SevaEngine:
         if self.precision not in ("f16", "fp8"):
             raise ValueError(f"unknown precision {self.precision!r} (f16 | fp8)")
         self.fp8 = self.precision == "fp8"
+        self.ff_fused = _os.environ.get("SEVA_FF_FUSED", "1") != "0"  # 0: two-kernel GEGLU + FF2 everywhere (A/B runs)
         self.p = model.params
         self.layout: Layout = model._layout
         self.arena = _Arena(self.device)
@@ -266,6 +267,12 @@ class SevaEngine:
             ops.gemm(a8, W[ff_pfx + ".w18"], w_exp=W[ff_pfx + ".w18e"], bias=W[ff_pfx + ".b1"], out_f8=h8, geglu=True)
             ops.gemm(h8, W[ff_pfx + ".w28"], w_exp=W[ff_pfx + ".w28e"], bias=W[ff_pfx + ".b2"], residual=residual,
                      out_f32=out_f32, out_f16=out_f16)
+            return
+        if self.ff_fused and c in ops.FF_FUSED_CHANNELS:
+            # narrow levels (ds1: C = 320): GEGLU -> FF2 in ONE kernel, the 4C-wide hidden tensor never exists in HBM
+            a = self._ln(x32, ln_pfx, rows, c)
+            ops.ff_fused(a, W[ff_pfx + ".w1"], W[ff_pfx + ".b1"], W[ff_pfx + ".w2"], W[ff_pfx + ".b2"],
+                         residual=residual, out_f32=out_f32, out_f16=out_f16)
             return
         step = self._slice_rows(rows, c, unit)
         a_buf = self._buf("ln16", (step, c), F16)

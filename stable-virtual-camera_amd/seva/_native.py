@@ -40,6 +40,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class FfDesc(C.Structure):
+    _fields_ = [
+        ("a", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
+        ("residual", c_void_p), ("out_f32", c_void_p), ("out_f16", c_void_p),
+        ("M", c_int64), ("lda", c_int64), ("ldr", c_int64), ("ldo32", c_int64), ("ldo16", c_int64),
+        ("C", c_int32),
+    ]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p),
@@ -69,6 +78,7 @@ SYMBOLS = {
     "seva_target_arch": (c_char_p, []),
     "seva_gemm_f16": (c_int, [POINTER(GemmDesc), c_void_p]),
     "seva_gemm_fp8": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "seva_ff_fused_f16": (c_int, [POINTER(FfDesc), c_void_p]),
     "seva_attention_f16": (c_int, [POINTER(AttnDesc), c_void_p]),
     "seva_groupnorm_f16": (c_int, [POINTER(GroupNormDesc), c_void_p]),
     "seva_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),

@@ -71,6 +71,28 @@ def gemm(
         check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(a.device)), "seva_gemm_f16")
 
 
+FF_FUSED_CHANNELS = (64, 128, 256, 320)
+
+
+def ff_fused(a: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, *,
+             residual: torch.Tensor | None = None, out_f32: torch.Tensor | None = None,
+             out_f16: torch.Tensor | None = None) -> None:
+    """out = W2 . geglu(W1 . a + b1) + b2 (+ residual) in one kernel (seva_ff_fused_f16); a: [M, C] f16, w1: [8C, C] f16
+    (interleaved GEGLU layout), w2: [C, 4C] f16; C in FF_FUSED_CHANNELS."""
+    require_cuda(a, w1, w2)
+    M, c = a.shape
+    assert a.dtype == F16 and w1.dtype == F16 and w2.dtype == F16 and w1.shape == (8 * c, c) and w2.shape == (c, 4 * c)
+    assert w1.is_contiguous() and w2.is_contiguous() and c in FF_FUSED_CHANNELS
+    d = nv.FfDesc()
+    d.a, d.w1, d.b1, d.w2, d.b2 = a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    d.residual, d.out_f32, d.out_f16 = ptr(residual), ptr(out_f32), ptr(out_f16)
+    d.M, d.lda, d.C = M, a.stride(0), c
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.ldo32 = out_f32.stride(0) if out_f32 is not None else 0
+    d.ldo16 = out_f16.stride(0) if out_f16 is not None else 0
+    check(_lib().seva_ff_fused_f16(C.byref(d), stream_ptr(a.device)), "seva_ff_fused_f16")
+
+
 def conv3x3(
     x: torch.Tensor,
     w: torch.Tensor,

@@ -73,6 +73,23 @@ def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, resid
     _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu, out_f8)
 
 
+FF_FUSED_CHANNELS = (64, 128, 256, 320)
+
+
+def ff_fused(a, w1, b1, w2, b2, *, residual=None, out_f32=None, out_f16=None):
+    M, c = a.shape
+    assert a.dtype == F16 and w1.shape == (8 * c, c) and w2.shape == (c, 4 * c) and c in FF_FUSED_CHANNELS
+    y = (a.float() @ w1.float().T + b1).view(M, -1, 2, 32)
+    h = (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(M, 4 * c).half().float()  # hidden rounded to f16 once
+    acc = h @ w2.float().T + b2
+    if residual is not None:
+        acc = acc + residual.reshape(M, -1)[:, :c]
+    if out_f32 is not None:
+        out_f32.view(M, -1)[:, :c].copy_(acc)
+    if out_f16 is not None:
+        out_f16.view(M, -1)[:, :c].copy_(acc.half())
+
+
 def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
             ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None):
     n, ih, iw, cin = x.shape

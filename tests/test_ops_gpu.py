@@ -579,3 +579,38 @@ def test_value_dict_and_cond_assembly(dev):
     for k in c_ref:
         assert torch.equal(c[k].cpu(), c_ref[k]), k
         assert torch.equal(uc[k].cpu(), uc_ref[k]), k
+
+
+@pytest.mark.parametrize("M,C", [(300, 64), (1000, 128), (515, 256), (2049, 320), (128, 320), (77, 320)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res):
+    """seva_ff_fused_f16 (GEGLU -> FF2 in one kernel, hidden activations in registers) against (a) the two-kernel path it
+    replaces -- same f16 rounding of the hidden tensor, so they agree to fp32 accumulation-order noise -- and (b) fp32 torch."""
+    from seva import ops
+    from seva._engine import interleave_geglu
+    g = torch.Generator().manual_seed(91)
+    a = torch.randn(M, C, generator=g).half().to(dev)
+    w1 = (torch.randn(8 * C, C, generator=g) * C ** -0.5).half().to(dev)
+    b1 = (0.3 * torch.randn(8 * C, generator=g)).to(dev)
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).half().to(dev)
+    b2 = (0.3 * torch.randn(C, generator=g)).to(dev)
+    res = torch.randn(M, C, generator=g).to(dev) if with_res else None
+    wi, bi = interleave_geglu(w1, b1)
+    o32 = torch.full((M, C), float("nan"), device=dev)
+    o16 = torch.full((M, C), float("nan"), device=dev, dtype=torch.float16)
+    ops.ff_fused(a, wi, bi, w2, b2, residual=res, out_f32=o32, out_f16=o16)
+    hid = torch.empty((M, 4 * C), device=dev, dtype=torch.float16)
+    ops.gemm(a, wi, bias=bi, out_f16=hid, geglu=True)
+    two = torch.empty((M, C), device=dev)
+    ops.gemm(hid, w2, bias=b2, residual=res, out_f32=two)
+    y = a.float() @ w1.float().T + b1
+    ref = (y[:, : 4 * C] * F.gelu(y[:, 4 * C:])) @ w2.float().T + b2 + (res if with_res else 0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o32).all()
+    e_two, e_ref = rel_l2(o32, two), rel_l2(o32, ref)
+    assert e_two < 2e-5, e_two
+    assert e_ref < 1e-3, e_ref
+    assert torch.equal(o16, o32.half())
+    o16b = torch.full((M, C), float("nan"), device=dev, dtype=torch.float16)  # f16-only output (time-mix tail)
+    ops.ff_fused(a, wi, bi, w2, b2, residual=res, out_f16=o16b)
+    assert torch.equal(o16b, o16)
