@@ -291,7 +291,7 @@ int seva_attention_small_f16(const void* q, const void* k, const void* v, void* 
  * Benchmark / debugging knobs.  The library reads its SEVA_* environment variables ONCE, when it is loaded (nothing
  * on the launch path calls getenv); a host changes a knob at run time with seva_set_knob (tests, tools).  Names:
  * gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat, attn_dbg, attn_no_tr, attn_two,
- * gn_min_iter (environment: SEVA_ + upper case).  -1 = unset (default heuristics).  None is needed in production.
+ * gn_min_iter, ff_variant (environment: SEVA_ + upper case).  -1 = unset (default heuristics).  None is needed in production.
  */
 int seva_set_knob(const char* name, int32_t value);
 int seva_get_knob(const char* name, int32_t* value);

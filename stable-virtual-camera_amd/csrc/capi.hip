@@ -36,7 +36,7 @@ const KnobEntry kKnobs[] = {
     {"gemm_bm", "SEVA_GEMM_BM", &SevaKnobs::gemm_bm}, {"gemm_bn", "SEVA_GEMM_BN", &SevaKnobs::gemm_bn},
     {"gemm_astat", "SEVA_GEMM_ASTAT", &SevaKnobs::gemm_astat}, {"attn_dbg", "SEVA_ATTN_DBG", &SevaKnobs::attn_dbg},
     {"attn_no_tr", "SEVA_ATTN_NO_TR", &SevaKnobs::attn_no_tr}, {"attn_two", "SEVA_ATTN_TWO", &SevaKnobs::attn_two},
-    {"gn_min_iter", "SEVA_GN_MIN_ITER", &SevaKnobs::gn_min_iter},
+    {"gn_min_iter", "SEVA_GN_MIN_ITER", &SevaKnobs::gn_min_iter}, {"ff_variant", "SEVA_FF_VARIANT", &SevaKnobs::ff_variant},
 };
 SevaKnobs knobs_from_env() {
   SevaKnobs k;

@@ -35,6 +35,7 @@ struct SevaKnobs {
   int gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat;
   int attn_dbg, attn_no_tr, attn_two;
   int gn_min_iter;
+  int ff_variant;
 };
 extern SevaKnobs g_seva_knobs;
 

@@ -583,11 +583,13 @@ def test_value_dict_and_cond_assembly(dev):
 
 @pytest.mark.parametrize("M,C", [(300, 64), (1000, 128), (515, 256), (2049, 320), (128, 320), (77, 320)])
 @pytest.mark.parametrize("with_res", [True, False])
-def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res):
+@pytest.mark.parametrize("variant", [8, 4])
+def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res, variant, knobs):
     """seva_ff_fused_f16 (GEGLU -> FF2 in one kernel, hidden activations in registers) against (a) the two-kernel path it
     replaces -- same f16 rounding of the hidden tensor, so they agree to fp32 accumulation-order noise -- and (b) fp32 torch."""
     from seva import ops
     from seva._engine import interleave_geglu
+    knobs(ff_variant=variant)  # 8 (default): two waves per row group; 4: one wave per row group, 512 registers
     g = torch.Generator().manual_seed(91)
     a = torch.randn(M, C, generator=g).half().to(dev)
     w1 = (torch.randn(8 * C, C, generator=g) * C ** -0.5).half().to(dev)

@@ -31,6 +31,12 @@ def fused():
     ops.ff_fused(a, wi, bi, w2, b2, residual=res, out_f32=o_f)
 
 
+def fused4():
+    ops.set_knob("ff_variant", 4)
+    ops.ff_fused(a, wi, bi, w2, b2, residual=res, out_f32=o_f)
+    ops.set_knob("ff_variant", -1)
+
+
 def timeit(fn, reps=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,7 +49,7 @@ def timeit(fn, reps=10):
 
 flop = 2.0 * M * C * 8 * C + 2.0 * M * 4 * C * C
 for rnd in range(3):
-    t2, tf = timeit(two), timeit(fused)
-    print(f"round {rnd}: two kernels {t2:8.1f} us ({flop / t2 / 1e6:6.1f} TFLOP/s) | fused {tf:8.1f} us ({flop / tf / 1e6:6.1f} TFLOP/s) "
-          f"| x{t2 / tf:.2f}", flush=True)
+    t2, tf, t4 = timeit(two), timeit(fused), timeit(fused4)
+    print(f"round {rnd}: two kernels {t2:8.1f} us ({flop / t2 / 1e6:6.1f} TFLOP/s) | fused 8-wave {tf:8.1f} us ({flop / tf / 1e6:6.1f} TFLOP/s) "
+          f"x{t2 / tf:.2f} | fused 4-wave {t4:8.1f} us x{t2 / t4:.2f}", flush=True)
 print("rel-L2 fused vs two-kernel:", float((o_f - o_two).norm() / o_two.norm()))
