@@ -149,8 +149,9 @@ int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream);
  * Replaces GroupNorm32 + SiLU + dense_emb_layers of seva/modules/layers.py:61-63,98-100,
  * 106-111,122-131, the output head norm (seva/model.py:171) and the transformer input norm
  * (seva/modules/transformer.py:186,231).
- * workspace: at least n * 64 * groups * 2 floats.
+ * workspace: at least n * 1024 * groups * 2 floats (SEVA_GN_WORKSPACE_SLABS slab slots per sample).
  */
+#define SEVA_GN_WORKSPACE_SLABS 1024
 typedef struct seva_groupnorm_desc {
   const float* x1; /* [n][hw][c1] */
   const float* x2; /* [n][hw][c2] or NULL */

@@ -13,7 +13,8 @@ namespace {
 
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_THREADS = 1024;
-constexpr int GN_MAX_SLABS = 64;
+constexpr int GN_MAX_SLABS = 1024;  // slab slots per sample in the workspace (the last one holds the finalised statistics)
+constexpr int GN_BASE_SLABS = 64;   // slab cap of images up to 8192 pixels (every UNet level)
 constexpr int GN_MAX_GROUPS = 32;
 constexpr int GN_MAX_DENSE = 8;
 
@@ -96,17 +97,17 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(GnArgs p) {
   }
 }
 
-// Slab partials -> (mean, rstd) per (sample, group), once, in fp64, in slab order (deterministic).  Stored behind the
-// slab area of the workspace (the statistics pass uses at most GN_MAX_SLABS - 1 of the 64 slab slots per sample).
+// Slab partials -> (mean, rstd) per (sample, group), once, in fp64, in a fixed order (deterministic).  Stored behind the
+// slab area of the workspace (the statistics pass uses at most GN_MAX_SLABS - 1 of the slab slots per sample).
 __global__ void gn_finalize_kernel(GnArgs p) {
-  // one wave per (sample, group): lane l takes slab l (nslab_stats <= 63), then a fixed xor-shuffle tree in fp64
+  // one wave per (sample, group): lane l takes slabs l, l + 64, ... in order, then a fixed xor-shuffle tree in fp64
   const int n = blockIdx.x, g = blockIdx.y, l = threadIdx.x;
   const int C = p.c1 + p.c2, cpg = C / p.groups;
   double s = 0.0, ss = 0.0;
-  if (l < p.nslab_stats) {
-    const float* o = p.ws + (((int64_t)n * p.nslab_stats + l) * p.groups + g) * 2;
-    s = (double)o[0];
-    ss = (double)o[1];
+  for (int sl = l; sl < p.nslab_stats; sl += 64) {
+    const float* o = p.ws + (((int64_t)n * p.nslab_stats + sl) * p.groups + g) * 2;
+    s += (double)o[0];
+    ss += (double)o[1];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -394,7 +395,12 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   const int plc = nthreads / tpp;
   // the statistics partition depends on the per-sample shape only (never on n): a sample's result
   // is bit-identical whatever else is in the batch
-  a.nslab_stats = clampi(d->hw / (plc * 16), 1, GN_MAX_SLABS - 1);
+  // Slabs of the statistics pass: a function of the IMAGE only (never of the batch: a sample's statistics are bitwise the
+  // same whatever it is batched with).  Up to 63 for the UNet's images (<= 8192 pixels: with 42 samples that is 2.6k
+  // workgroups); large single images (VAE at 576x576: 331,776 pixels, batch 1) get up to 1023, otherwise 63 workgroups
+  // would read a 170 MB tensor alone (measured: 37 % of a VAE decode, 290 GB/s).
+  const int slab_cap = clampi(d->hw / 128, GN_BASE_SLABS - 1, GN_MAX_SLABS - 1);
+  a.nslab_stats = clampi(d->hw / (plc * 16), 1, slab_cap);
   a.final_off = (int64_t)d->n * (GN_MAX_SLABS - 1) * d->groups * 2;
   // apply pass: block = whole pixels' worth of quads (cq <= 256: floor(256/cq) pixels per block, no idle tail
   // beyond the last partial wave) or an even split of the quads over gridDim.z blocks

@@ -558,7 +558,7 @@ class SevaEngine:
         assert y.ndim == 3
         lc = y.shape[1]
         t = t.to(torch.int64).contiguous()
-        self.gn_ws = self._buf("gn_ws", (n * 64 * 32 * 2,), F32)
+        self.gn_ws = self._buf("gn_ws", (n * ops.GN_WORKSPACE_SLABS * 32 * 2,), F32)
 
         # --- prologue: timestep embedding MLP, all ResBlock emb projections, folded cross-attn ---
         mc, ed = p.model_channels, lay.time_embed_dim

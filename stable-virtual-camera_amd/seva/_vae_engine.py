@@ -151,7 +151,7 @@ class VaeDecoderEngine(_VaeEngineBase):
         n, cz, h, w = z.shape
         if cz != self.latent:
             raise ValueError(f"expected {self.latent} latent channels, got {cz}")
-        self.gn_ws = self._buf("gn_ws", (n * 64 * 32 * 2,), F32)
+        self.gn_ws = self._buf("gn_ws", (n * ops.GN_WORKSPACE_SLABS * 32 * 2,), F32)
         inv = torch.full((n,), 1.0 / scale_factor, dtype=F32, device=self.device)
         z16 = self._buf("v_z16", (n, h * w, CIN_PAD), F16)
         ops.nchw_to_nhwc_f16(z, None, z16, scale=inv)                      # z / 0.18215, channels-last, padded
@@ -211,7 +211,7 @@ class VaeEncoderEngine(_VaeEngineBase):
         nd = len(self.block_out) - 1
         if h % (1 << nd) or w % (1 << nd):
             raise ValueError(f"VAE encode needs H and W divisible by {1 << nd} (got {h}x{w})")
-        self.gn_ws = self._buf("gn_ws", (n * 64 * 32 * 2,), F32)
+        self.gn_ws = self._buf("gn_ws", (n * ops.GN_WORKSPACE_SLABS * 32 * 2,), F32)
         one = torch.ones((n,), dtype=F32, device=self.device)
         x16 = self._buf("v_x16", (n, h * w, CIN_PAD), F16)
         ops.nchw_to_nhwc_f16(x, None, x16, scale=one)  # channels-last, 3 -> 64 zero-padded channels

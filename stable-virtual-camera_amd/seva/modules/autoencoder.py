@@ -205,8 +205,19 @@ class AutoEncoder(nn.Module):
     def _encode(self, x: torch.Tensor) -> torch.Tensor:
         return self.encoder_engine().encode(x, self.scale_factor)
 
-    def encode(self, x: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
+    def _frames_per_pass(self, chunk_size: int | None) -> int | None:
+        """`chunk_size` is the reference's memory knob (demo.py: AutoEncoder(chunk_size=1), decoding_t=1: 21 sequential
+        single-frame passes per window).  Every kernel of the VAE engines is sample-independent and bitwise batch-invariant
+        (GroupNorm slab counts depend on the image only; tested), so the frames-per-pass actually executed is a pure
+        performance choice: at 576x576 one decode pass costs 9.5 ms for 1 frame but 5.6 ms/frame for 7 (4 GB of arena per
+        frame; profiles/r02_kvae.log).  SEVA_VAE_FRAMES_PER_PASS (default 7) raises it; results are identical bit for bit."""
         chunk_size = chunk_size or self.chunk_size
+        if chunk_size is None:
+            return None
+        return max(int(chunk_size), int(os.environ.get("SEVA_VAE_FRAMES_PER_PASS", "7")))
+
+    def encode(self, x: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
+        chunk_size = self._frames_per_pass(chunk_size)
         if chunk_size is not None:
             return torch.cat([self._encode(xc) for xc in x.split(chunk_size)], dim=0)
         return self._encode(x)
@@ -215,7 +226,7 @@ class AutoEncoder(nn.Module):
         return self.engine().decode(z, self.scale_factor)
 
     def decode(self, z: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
-        chunk_size = chunk_size or self.chunk_size
+        chunk_size = self._frames_per_pass(chunk_size)
         if chunk_size is not None:
             return torch.cat([self._decode(zc) for zc in z.split(chunk_size)], dim=0)
         return self._decode(z)

@@ -174,8 +174,11 @@ def attention(
     check(_lib().seva_attention_f16(C.byref(d), stream_ptr(q.device)), "seva_attention_f16")
 
 
+GN_WORKSPACE_SLABS = 1024  # include/seva_hip.h SEVA_GN_WORKSPACE_SLABS
+
+
 def groupnorm_workspace(n: int, device) -> torch.Tensor:
-    return torch.empty(n * 64 * 32 * 2, dtype=F32, device=device)
+    return torch.empty(n * GN_WORKSPACE_SLABS * 32 * 2, dtype=F32, device=device)
 
 
 def groupnorm(
@@ -212,7 +215,7 @@ def groupnorm(
     d.silu, d.eps = 1 if silu else 0, eps
     d.raw_f16 = ptr(raw_f16)
     assert raw_f16 is None or (raw_f16.dtype == F16 and raw_f16.is_contiguous() and raw_f16.numel() == n * hw * (c1 + c2))
-    assert workspace.numel() >= n * 64 * groups * 2
+    assert workspace.numel() >= n * GN_WORKSPACE_SLABS * groups * 2
     check(_lib().seva_groupnorm_f16(C.byref(d), stream_ptr(x1.device)), "seva_groupnorm_f16")
 
 

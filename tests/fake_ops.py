@@ -124,8 +124,11 @@ def attention(q, k, v, out, *, nb0, nb1, heads, lq, lk, q_strides, k_strides, o_
     view(out, o_strides, lq).copy_(o.half())
 
 
+GN_WORKSPACE_SLABS = 1024  # include/seva_hip.h SEVA_GN_WORKSPACE_SLABS
+
+
 def groupnorm_workspace(n, device):
-    return torch.empty(n * 64 * 32 * 2, dtype=F32, device=device)
+    return torch.empty(n * GN_WORKSPACE_SLABS * 32 * 2, dtype=F32, device=device)
 
 
 def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, silu=False,
