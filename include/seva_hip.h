@@ -97,7 +97,7 @@ int seva_gemm_fp8(const seva_gemm_desc* d, seva_stream_t stream);
  *   out[m][:] = W2 . (v * gelu_erf(g)) + b2 (+ residual[m][:]),  [v ; g] = W1 . a[m][:] + b1
  * a: f16 [M][lda]; w1: f16 [8C][C] and b1: [8C] in the interleaved GEGLU layout of seva_gemm_f16 (groups of 64 rows =
  * [32 value | 32 gate]); w2: f16 [C][4C]; b2: [C].  The 4C-wide hidden activations stay in registers (rounded to f16
- * once, as the two-kernel form rounds the stored tensor); fp32 accumulation.
+ * once, as the two-kernel form rounds the stored tensor); fp32 accumulation.  The preceding LayerNorm can be folded in.
  */
 typedef struct seva_ff_desc {
   const void* a;
@@ -110,6 +110,13 @@ typedef struct seva_ff_desc {
   void* out_f16;         /* [M][ldo16] or NULL */
   int64_t M, lda, ldr, ldo32, ldo16;
   int32_t C;
+  /* optional LayerNorm prologue (transformer.py:102-104,141-143: ff(norm(x))): when ln_x is set the A operand is
+   * LayerNorm(ln_x) * ln_gamma + ln_beta computed in registers from fp32 rows [M][ldx] and `a` is ignored. */
+  const float* ln_x;
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t ldx;
+  float ln_eps;
 } seva_ff_desc;
 int seva_ff_fused_f16(const seva_ff_desc* d, seva_stream_t stream);
 

@@ -37,6 +37,12 @@ struct FfArgs {
   half_t* out_f16;
   int64_t M, lda, ldr, ldo32, ldo16;
   int32_t tiles_m;
+  // optional LayerNorm prologue (8-wave kernel): a = LayerNorm(ln_x) computed in registers, `a` unused
+  const float* ln_x;
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t ldx;
+  float ln_eps;
 };
 
 template <int N>
@@ -288,13 +294,65 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
   const int64_t m0 = (int64_t)tm * 128 + mr * 32;
 
   half8_t areg[2][KS];
+  if (p.ln_x) {
+    // LayerNorm prologue (reference transformer.py:102-104: x = ff(norm3(x)) + x): the wave's 32 rows are read as fp32, a
+    // row lives in the 4 lanes (fr, fg = 0..3) that hold its k = 32ks + 8fg + j; exact two-pass statistics with two
+    // xor-shuffles; the normalised row goes straight into the A fragments (one f16 rounding, as the LayerNorm kernel's
+    // output had).  Replaces a 95 us read-4B/write-2B pass + its re-read per feed-forward at the ds1 level.
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int64_t m = m0 + 16 * i + fr;
-    if (m >= p.M) m = p.M - 1;
-    const half_t* ap = p.a + m * p.lda + 8 * fg;
+    for (int i = 0; i < 2; ++i) {
+      int64_t m = m0 + 16 * i + fr;
+      if (m >= p.M) m = p.M - 1;
+      const float* xr = p.ln_x + m * p.ldx + 8 * fg;
+      f32x4 v[KS][2];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) areg[i][ks] = *(const half8_t*)(ap + 32 * ks);
+      for (int ks = 0; ks < KS; ++ks) {
+        v[ks][0] = *(const f32x4*)(xr + 32 * ks);
+        v[ks][1] = *(const f32x4*)(xr + 32 * ks + 4);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) sum += v[ks][e][0] + v[ks][e][1] + v[ks][e][2] + v[ks][e][3];
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum / (float)C;
+      float ss = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dlt = v[ks][e][r] - mean;
+            ss += dlt * dlt;
+          }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      const float rstd = rsqrtf(ss / (float)C + p.ln_eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        half_t y[8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const f32x4 g4 = *(const f32x4*)(p.ln_gamma + 32 * ks + 8 * fg + 4 * e);
+          const f32x4 b4 = *(const f32x4*)(p.ln_beta + 32 * ks + 8 * fg + 4 * e);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[4 * e + r] = (half_t)((v[ks][e][r] - mean) * rstd * g4[r] + b4[r]);
+        }
+        areg[i][ks] = half8_t{y[0], y[1], y[2], y[3], y[4], y[5], y[6], y[7]};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int64_t m = m0 + 16 * i + fr;
+      if (m >= p.M) m = p.M - 1;
+      const half_t* ap = p.a + m * p.lda + 8 * fg;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) areg[i][ks] = *(const half8_t*)(ap + 32 * ks);
+    }
   }
   f32x4 acc2[2][NJH];
 #pragma unroll
@@ -494,11 +552,14 @@ int ff_launch8(const FfArgs& a, hipStream_t s) {
 
 extern "C" int seva_ff_fused_f16(const seva_ff_desc* d, seva_stream_t stream) {
   SEVA_REQUIRE(d != nullptr, "ff_fused: null desc");
-  SEVA_REQUIRE(d->a && d->w1 && d->b1 && d->w2 && d->b2, "ff_fused: null operand");
+  SEVA_REQUIRE((d->a || d->ln_x) && d->w1 && d->b1 && d->w2 && d->b2, "ff_fused: null operand");
+  SEVA_REQUIRE(!d->ln_x || (d->ln_gamma && d->ln_beta && d->ldx >= d->C && d->ldx % 4 == 0 &&
+                            ((uintptr_t)d->ln_x | (uintptr_t)d->ln_gamma | (uintptr_t)d->ln_beta) % 16 == 0),
+               "ff_fused: LayerNorm prologue needs gamma, beta, a row pitch >= C (multiple of 4), 16-byte aligned pointers");
   SEVA_REQUIRE(d->out_f32 || d->out_f16, "ff_fused: no output");
   SEVA_REQUIRE(d->M > 0, "ff_fused: empty problem");
   SEVA_REQUIRE(d->C == 64 || d->C == 128 || d->C == 256 || d->C == 320, "ff_fused: C=%d unsupported (64, 128, 256, 320)", d->C);
-  SEVA_REQUIRE(d->lda >= d->C && d->lda % 8 == 0, "ff_fused: lda=%lld invalid", (long long)d->lda);
+  SEVA_REQUIRE(d->ln_x || (d->lda >= d->C && d->lda % 8 == 0), "ff_fused: lda=%lld invalid", (long long)d->lda);
   SEVA_REQUIRE((!d->residual || d->ldr % 4 == 0) && (!d->out_f32 || d->ldo32 % 4 == 0) && (!d->out_f16 || d->ldo16 % 4 == 0),
                "ff_fused: row pitches must be multiples of 4");
   SEVA_REQUIRE(((uintptr_t)d->a | (uintptr_t)d->w1 | (uintptr_t)d->b1 | (uintptr_t)d->w2 | (uintptr_t)d->b2 |
@@ -508,16 +569,17 @@ extern "C" int seva_ff_fused_f16(const seva_ff_desc* d, seva_stream_t stream) {
   a.a = (const half_t*)d->a; a.w1 = (const half_t*)d->w1; a.b1 = d->b1; a.w2 = (const half_t*)d->w2; a.b2 = d->b2;
   a.residual = d->residual; a.out_f32 = d->out_f32; a.out_f16 = (half_t*)d->out_f16;
   a.M = d->M; a.lda = d->lda; a.ldr = d->ldr; a.ldo32 = d->ldo32; a.ldo16 = d->ldo16;
+  a.ln_x = d->ln_x; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ldx = d->ldx; a.ln_eps = d->ln_eps;
   const int64_t tiles = (d->M + 127) / 128;
   SEVA_REQUIRE(tiles <= 0x7fffffff, "ff_fused: too many rows");
   a.tiles_m = (int)tiles;
   hipStream_t s = (hipStream_t)stream;
   const double C = (double)d->C;
   const double flops = 2.0 * (double)d->M * C * (8.0 * C) + 2.0 * (double)d->M * (4.0 * C) * C;
-  const double bytes = (double)d->M * C * (2.0 + (d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) + (d->out_f16 ? 2.0 : 0.0)) +
+  const double bytes = (double)d->M * C * ((d->ln_x ? 4.0 : 2.0) + (d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) + (d->out_f16 ? 2.0 : 0.0)) +
                        2.0 * (8.0 * C * C + 4.0 * C * C);
   SevaProfScope prof(0, flops, s, bytes);
-  if (g_seva_knobs.ff_variant == 4) {  // knob ff_variant = 4: the 4-wave kernel (benchmarking); default: 8 waves
+  if (g_seva_knobs.ff_variant == 4 && !d->ln_x) {  // knob ff_variant = 4: the 4-wave kernel (benchmarking); default: 8 waves
     switch (d->C) {
       case 64: return ff_launch<64>(a, s);
       case 128: return ff_launch<128>(a, s);

@@ -270,9 +270,10 @@ class SevaEngine:
             return
         if self.ff_fused and c in ops.FF_FUSED_CHANNELS:
             # narrow levels (ds1: C = 320): GEGLU -> FF2 in ONE kernel, the 4C-wide hidden tensor never exists in HBM
-            a = self._ln(x32, ln_pfx, rows, c)
-            ops.ff_fused(a, W[ff_pfx + ".w1"], W[ff_pfx + ".b1"], W[ff_pfx + ".w2"], W[ff_pfx + ".b2"],
-                         residual=residual, out_f32=out_f32, out_f16=out_f16)
+            # ... and its LayerNorm runs in that kernel's prologue (x32 rows read as fp32, normalised in registers)
+            ops.ff_fused(None, W[ff_pfx + ".w1"], W[ff_pfx + ".b1"], W[ff_pfx + ".w2"], W[ff_pfx + ".b2"],
+                         residual=residual, out_f32=out_f32, out_f16=out_f16,
+                         ln_x=x32, ln_gamma=W[ln_pfx + ".g"], ln_beta=W[ln_pfx + ".b"], ln_eps=1e-5)
             return
         step = self._slice_rows(rows, c, unit)
         a_buf = self._buf("ln16", (step, c), F16)

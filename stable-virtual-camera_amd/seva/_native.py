@@ -46,6 +46,7 @@ class FfDesc(C.Structure):
         ("residual", c_void_p), ("out_f32", c_void_p), ("out_f16", c_void_p),
         ("M", c_int64), ("lda", c_int64), ("ldr", c_int64), ("ldo32", c_int64), ("ldo16", c_int64),
         ("C", c_int32),
+        ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ldx", c_int64), ("ln_eps", c_float),
     ]
 
 

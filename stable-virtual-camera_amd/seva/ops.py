@@ -74,19 +74,25 @@ def gemm(
 FF_FUSED_CHANNELS = (64, 128, 256, 320)
 
 
-def ff_fused(a: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, *,
+def ff_fused(a: torch.Tensor | None, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, *,
              residual: torch.Tensor | None = None, out_f32: torch.Tensor | None = None,
-             out_f16: torch.Tensor | None = None) -> None:
+             out_f16: torch.Tensor | None = None, ln_x: torch.Tensor | None = None,
+             ln_gamma: torch.Tensor | None = None, ln_beta: torch.Tensor | None = None, ln_eps: float = 1e-5) -> None:
     """out = W2 . geglu(W1 . a + b1) + b2 (+ residual) in one kernel (seva_ff_fused_f16); a: [M, C] f16, w1: [8C, C] f16
-    (interleaved GEGLU layout), w2: [C, 4C] f16; C in FF_FUSED_CHANNELS."""
-    require_cuda(a, w1, w2)
-    M, c = a.shape
-    assert a.dtype == F16 and w1.dtype == F16 and w2.dtype == F16 and w1.shape == (8 * c, c) and w2.shape == (c, 4 * c)
+    (interleaved GEGLU layout), w2: [C, 4C] f16; C in FF_FUSED_CHANNELS.  With ln_x ([M, C] f32) the A operand is
+    LayerNorm(ln_x) * ln_gamma + ln_beta, computed in the kernel's prologue (a = None)."""
+    src = ln_x if ln_x is not None else a
+    require_cuda(src, w1, w2)
+    M, c = src.shape
+    assert (ln_x is not None and ln_x.dtype == F32 and ln_gamma is not None and ln_beta is not None) or a.dtype == F16
+    assert w1.dtype == F16 and w2.dtype == F16 and w1.shape == (8 * c, c) and w2.shape == (c, 4 * c)
     assert w1.is_contiguous() and w2.is_contiguous() and c in FF_FUSED_CHANNELS
     d = nv.FfDesc()
-    d.a, d.w1, d.b1, d.w2, d.b2 = a.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    d.a, d.w1, d.b1, d.w2, d.b2 = ptr(a) if ln_x is None else None, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    if ln_x is not None:
+        d.ln_x, d.ln_gamma, d.ln_beta, d.ldx, d.ln_eps = ln_x.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), ln_x.stride(0), ln_eps
     d.residual, d.out_f32, d.out_f16 = ptr(residual), ptr(out_f32), ptr(out_f16)
-    d.M, d.lda, d.C = M, a.stride(0), c
+    d.M, d.lda, d.C = M, (a.stride(0) if ln_x is None else 0), c
     d.ldr = residual.stride(0) if residual is not None else 0
     d.ldo32 = out_f32.stride(0) if out_f32 is not None else 0
     d.ldo16 = out_f16.stride(0) if out_f16 is not None else 0

@@ -76,7 +76,11 @@ def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, resid
 FF_FUSED_CHANNELS = (64, 128, 256, 320)
 
 
-def ff_fused(a, w1, b1, w2, b2, *, residual=None, out_f32=None, out_f16=None):
+def ff_fused(a, w1, b1, w2, b2, *, residual=None, out_f32=None, out_f16=None, ln_x=None, ln_gamma=None, ln_beta=None,
+             ln_eps=1e-5):
+    if ln_x is not None:
+        c = ln_x.shape[-1]
+        a = F.layer_norm(ln_x.reshape(-1, c), (c,), ln_gamma, ln_beta, ln_eps).half()
     M, c = a.shape
     assert a.dtype == F16 and w1.shape == (8 * c, c) and w2.shape == (c, 4 * c) and c in FF_FUSED_CHANNELS
     y = (a.float() @ w1.float().T + b1).view(M, -1, 2, 32)

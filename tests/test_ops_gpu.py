@@ -616,3 +616,15 @@ def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res, variant, knobs):
     o16b = torch.full((M, C), float("nan"), device=dev, dtype=torch.float16)  # f16-only output (time-mix tail)
     ops.ff_fused(a, wi, bi, w2, b2, residual=res, out_f16=o16b)
     assert torch.equal(o16b, o16)
+    if variant == 8:
+        # LayerNorm folded into the prologue: vs LayerNorm kernel -> fused kernel (same math, different summation order)
+        x = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dev)
+        gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+        a_ln = torch.empty((M, C), device=dev, dtype=torch.float16)
+        ops.layernorm(x, gm, bt, a_ln)
+        want = torch.empty((M, C), device=dev)
+        ops.ff_fused(a_ln, wi, bi, w2, b2, residual=res, out_f32=want)
+        got = torch.full((M, C), float("nan"), device=dev)
+        ops.ff_fused(None, wi, bi, w2, b2, residual=res, out_f32=got, ln_x=x, ln_gamma=gm, ln_beta=bt)
+        e_ln = rel_l2(got, want)
+        assert torch.isfinite(got).all() and e_ln < 2e-4, e_ln  # f16 roundings of the normalised row flip at ties only
