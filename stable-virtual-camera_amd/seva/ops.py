@@ -96,7 +96,7 @@ def ff_fused(a: torch.Tensor | None, w1: torch.Tensor, b1: torch.Tensor, w2: tor
     d.ldr = residual.stride(0) if residual is not None else 0
     d.ldo32 = out_f32.stride(0) if out_f32 is not None else 0
     d.ldo16 = out_f16.stride(0) if out_f16 is not None else 0
-    check(_lib().seva_ff_fused_f16(C.byref(d), stream_ptr(a.device)), "seva_ff_fused_f16")
+    check(_lib().seva_ff_fused_f16(C.byref(d), stream_ptr(src.device)), "seva_ff_fused_f16")
 
 
 def conv3x3(
