@@ -302,25 +302,37 @@ def main():
         from seva.modules.autoencoder import AutoEncoder
 
         ae = AutoEncoder(chunk_size=1, random_init=True).to(device)
-        zl = (x[:2] / x[:2].std() * 0.18215).contiguous()
+        zl = (x[:7] / x[:7].std() * 0.18215).contiguous()  # 7 frames per pass (AutoEncoder's default execution chunk)
         with torch.no_grad():
-            ae.decode(zl[:1])
+            ae.decode(zl)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             img = ae.decode(zl)
             torch.cuda.synchronize()
         dtv = (time.perf_counter() - t1) / zl.shape[0]
         with torch.no_grad():  # encode of the input / anchor views (reference autoencoder.py:21-35), chunk_size=1
-            ae.encode(img[:1])
+            ae.encode(img)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             ae.encode(img)
             torch.cuda.synchronize()
         dte = (time.perf_counter() - t1) / img.shape[0]
         vae = {"ms_per_frame": dtv * 1e3, "frames_per_sec": 1.0 / dtv, "frame": f"{img.shape[-2]}x{img.shape[-1]}",
-               "encode_ms_per_frame": dte * 1e3,
+               "encode_ms_per_frame": dte * 1e3, "frames_per_pass": int(zl.shape[0]),
                "weights": "random-init SD-2.1 VAE topology (parity unpinned)"}
         del ae
+        # CLIP ViT-H-14 image conditioner (reference conditioner.py:36-39), once per window on the input views, outside `value`
+        from seva.modules.conditioner import CLIPConditioner
+
+        clip = CLIPConditioner(random_init=True).to(device)
+        with torch.no_grad():
+            clip(img[:1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            clip(img[:1])
+            torch.cuda.synchronize()
+        vae["clip_conditioner_ms_per_frame"] = (time.perf_counter() - t1) * 1e3
+        del clip
 
     if rank == 0:
         cpu = None

@@ -3,8 +3,10 @@
 (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with --kernel-trace, eager launches).
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of wide coalesced
-reads (MI355X_MICROARCH.md §HBM), so reads are doubled.  Writes `profiles/r01_traffic.json`:
-{class: {"bytes_per_launch": ..., "launches": ..., "read_bytes": ..., "write_bytes": ...}}.
+reads (MI355X_MICROARCH.md §HBM), so reads are doubled -- that correction is calibrated for 16-B-per-lane streaming reads
+only; the guide calls other access widths uncalibrated, so read the absolute number as an upper estimate and use it
+for comparisons between builds.  Writes `profiles/rNN_traffic.json`:
+{class: {"bytes_per_launch": ..., "launches": ..., "read_bytes": ..., "write_bytes": ...}, "git": ..., "command": ...}.
 """
 import csv
 import glob
@@ -15,7 +17,7 @@ import sys
 import re
 
 # kernel names: gemm_kernel<BM, BN, MODE, EPI, DBG> (MODE 0 plain / 1 conv3x3), attn_kernel<NW, KT, ...>
-CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128), (128|160), 0, "), "conv": re.compile(r"gemm_kernel<(64|128), (128|160), [12], "),
+CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128), (128|160), 0, |ff_fused"), "conv": re.compile(r"gemm_kernel<(64|128), (128|160), [12], "),
            "attention": re.compile(r"attn_kernel<4, 64")}
 
 
@@ -44,5 +46,11 @@ if __name__ == "__main__":
             res[cls] = {"bytes_per_launch": (read_b + write_b) / n, "launches": n,
                         "read_bytes": read_b, "write_bytes": write_b,
                         "note": "FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE, summed over all launches of the class in one eager step"}
+    import subprocess
+    try:
+        res["git"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("SEVA_GIT_REV")
+    except Exception:
+        res["git"] = os.environ.get("SEVA_GIT_REV")
+    res["command"] = os.environ.get("SEVA_TRAFFIC_COMMAND", "SEVA_HIPGRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
