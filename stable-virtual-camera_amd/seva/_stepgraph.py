@@ -41,7 +41,9 @@ class StepGraph:
         self._refresh(inputs)
         self.graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: HIP calls of OTHER threads (e.g. the RCCL watchdog of a multi-GPU job polling its events)
+        # neither join nor invalidate this capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_out = fn(*self.static_in)
         self.replays = 0
 

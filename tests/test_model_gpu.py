@@ -520,3 +520,67 @@ def test_to_d_and_euler_step_kernels(dev):
     xn = x + eps * (sh ** 2 - sg ** 2) ** 0.5
     dd = (xn - 0.5 * xn) / sh
     assert torch.allclose(o, xn + (2.0 - sh) * dd, rtol=1e-5, atol=1e-5)
+
+
+def test_tracked_sampler_subclass_protocol(dev, tiny):
+    """The way the reference's `GradioTrackedSampler` (seva/eval.py:1037-1089) drives the sampler: a subclass that calls
+    `prepare_sampling_loop`, `get_sigma_gen` and `sampler_step` itself, compares `sigmas[i]` with Python floats, polls an abort flag per
+    step and returns None when aborted.  Must give the same result as `__call__` (whole-step hipGraph included) and abort cleanly."""
+    import threading
+    from seva import sampling as S
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+    net, _ = tiny
+    T, hw, steps = 4, 16, 5
+
+    class Tracked(S.EulerEDMSampler):
+        def __init__(self, *a, abort_event=None, **k):
+            super().__init__(*a, **k)
+            self.abort_event = abort_event
+            self.steps_done = 0
+
+        def __call__(self, denoiser, x, scale, cond, uc=None, num_steps=None, verbose=True, **guider_kwargs):
+            uc = cond if uc is None else uc
+            x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+            for i in self.get_sigma_gen(num_sigmas, verbose=verbose):
+                gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
+                x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, scale, cond, uc, gamma, **guider_kwargs)
+                self.steps_done += 1
+                if self.abort_event is not None and self.abort_event.is_set():
+                    return None
+            return x
+
+    g = torch.Generator().manual_seed(13)
+    eps = [torch.randn(T, 4, hw, hw, generator=g) for _ in range(steps)]
+    sc = synth.synth_scene(T, (hw, hw), (0,), seed=23)
+    disc = S.DDPMDiscretization()
+    den = S.DiscreteDenoiser(disc, num_idx=1000, device=dev)
+    wrap = SGMWrapper(net)
+
+    def run(sampler):
+        it = iter(eps)
+        sampler.noise_fn = lambda x: next(it).to(x.device)
+        cond = {k: v.to(dev) for k, v in sc["cond"].items()}
+        uc = {k: v.to(dev) for k, v in sc["uc"].items()}
+        with torch.inference_mode():
+            out = sampler(lambda x, s, c: den(wrap, x, s, c, num_frames=T), sc["noise"].to(dev), scale=2.0, cond=cond, uc=uc,
+                          verbose=False, c2w=sc["c2w"].to(dev), K=sc["K"].to(dev), input_frame_mask=sc["input_frame_mask"].to(dev))
+            return None if out is None else out.clone()
+
+    mk = lambda cls, **k: cls(disc, S.MultiviewCFG(1.2), num_steps=steps, verbose=False, device=dev, s_churn=0.0, **k)  # noqa: E731
+    ref = run(mk(S.EulerEDMSampler))
+    tracked = mk(Tracked)
+    got = run(tracked)
+    assert tracked.steps_done == steps and torch.equal(got, ref)
+    ev = threading.Event()
+    aborting = mk(Tracked, abort_event=ev)
+    orig = aborting.sampler_step
+
+    def step_then_abort(*a, **k):
+        out = orig(*a, **k)
+        if aborting.steps_done == 1:
+            ev.set()
+        return out
+
+    aborting.sampler_step = step_then_abort
+    assert run(aborting) is None and aborting.steps_done == 2
