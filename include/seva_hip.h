@@ -178,6 +178,8 @@ typedef struct seva_groupnorm_desc {
   /* optional e4m3 output (saturating), same layout: the A operand of seva_gemm_fp8 / an fp8 conv.  When set, out_f16
    * may be NULL. */
   void* out_f8;
+  int64_t ld_out_f8; /* pixel pitch of out_f8 in bytes (>= c1 + c2; 0 = c1 + c2): lets a 320-channel tensor feed an fp8 conv whose
+                      * channel count is padded to a multiple of 128 (pad bytes are never written: keep them zero) */
 } seva_groupnorm_desc;
 int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
 
@@ -186,7 +188,8 @@ int seva_layernorm_f16(const float* x, const float* gamma, const float* beta, vo
                        int64_t rows, int32_t c, float eps, seva_stream_t stream);
 /* Same normalisation with OCP e4m3 output (saturating at +-448): the A operand of seva_gemm_fp8. */
 int seva_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* out_f8, int64_t rows,
-                       int32_t c, float eps, seva_stream_t stream);
+                       int32_t c, float eps, int64_t ld_out /* row pitch in bytes, >= c; 0 = c; pad bytes untouched */,
+                       seva_stream_t stream);
 
 /* Row softmax: out[r][c] = softmax_c(x[r][c] * scale) as f16 for c < cols; columns cols..cols_pad-1
  * of `out` are written as 0 (so `out` can be the K-padded A operand of the following P*V GEMM).

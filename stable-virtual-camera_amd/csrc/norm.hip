@@ -27,7 +27,8 @@ struct GnArgs {
   const float* dense_w;
   const float* dense_b;
   half_t* out;      // f16 output (may be null when out8 is set)
-  uint8_t* out8;    // optional: e4m3 output (A operand of an fp8 GEMM / conv), same layout
+  uint8_t* out8;    // optional: e4m3 output (A operand of an fp8 GEMM / conv), pixel pitch ld8 (>= C; pad bytes untouched)
+  int64_t ld8;
   half_t* raw_out;  // optional: plain f16 copy of the (concatenated) input, same layout as out
   float* ws;
   int32_t n, hw, c1, c2, groups, dense_c, silu;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
         }
         if (pix < p_end) {
           if (p.out) *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
-          if (p.out8) *(int*)(p.out8 + ((int64_t)n * p.hw + pix) * C + c0) = pack_fp8x4(y4[0], y4[1], y4[2], y4[3]);
+          if (p.out8) *(int*)(p.out8 + ((int64_t)n * p.hw + pix) * p.ld8 + c0) = pack_fp8x4(y4[0], y4[1], y4[2], y4[3]);
           if (p.raw_out) {  // the un-normalised input as f16: A operand of the ResBlock's 1x1 skip conv
             const half4_t hr = {(half_t)v[u][0], (half_t)v[u][1], (half_t)v[u][2], (half_t)v[u][3]};
             *(half4_t*)(p.raw_out + ((int64_t)n * p.hw + pix) * C + c0) = hr;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         half_t* __restrict__ out, int64_t rows,
-                                                        int c, float eps) {  // OUT 1 / 2: `out` is an e4m3 / fp32 buffer
+                                                        int c, float eps, int64_t ld_out) {  // OUT 1 / 2: `out` is an e4m3 / fp32 buffer
   const int sub = threadIdx.x & 15;
   const int cq = c >> 2;
   // group g of the block owns rows base + g, base + g + 16, ... (consecutive groups touch consecutive rows per pass)
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
     const float rstd = rsqrtf(group16_sum(ss) / (float)c + eps);
     if (row < rows) {
-      half_t* orow = out + row * c;
+      half_t* orow = out + row * ld_out;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int i = sub + 16 * k;
@@ -324,8 +325,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = (v[k][r] - mean) * rstd * g4[r] + b4[r];
-            if constexpr (OUT == 1) *(int*)((uint8_t*)out + row * c + i * 4) = pack_fp8x4(y[0], y[1], y[2], y[3]);
-            else *(f32x4*)((float*)out + row * c + i * 4) = f32x4{y[0], y[1], y[2], y[3]};
+            if constexpr (OUT == 1) *(int*)((uint8_t*)out + row * ld_out + i * 4) = pack_fp8x4(y[0], y[1], y[2], y[3]);
+            else *(f32x4*)((float*)out + row * ld_out + i * 4) = f32x4{y[0], y[1], y[2], y[3]};
           } else {
             half4_t h;
 #pragma unroll
@@ -386,6 +387,8 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   a.x1 = d->x1; a.x2 = d->x2; a.gamma = d->gamma; a.beta = d->beta;
   a.dense = d->dense; a.dense_w = d->dense_w; a.dense_b = d->dense_b;
   a.out = (half_t*)d->out_f16; a.out8 = (uint8_t*)d->out_f8; a.raw_out = (half_t*)d->raw_f16; a.ws = d->workspace;
+  a.ld8 = d->ld_out_f8 > 0 ? d->ld_out_f8 : C;
+  SEVA_REQUIRE(a.ld8 >= C && a.ld8 % 4 == 0, "groupnorm: ld_out_f8=%lld invalid", (long long)a.ld8);
   a.n = d->n; a.hw = d->hw; a.c1 = d->c1; a.c2 = d->c2; a.groups = d->groups;
   a.dense_c = d->dense_c; a.silu = d->silu; a.eps = d->eps;
   const int cq = C / 4;
@@ -435,8 +438,10 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
 namespace {
 template <int OUT>
 int layernorm_entry(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int32_t c, float eps,
-                    seva_stream_t stream) {
+                    seva_stream_t stream, int64_t ld_out = 0) {
   SEVA_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
+  if (ld_out <= 0) ld_out = c;
+  SEVA_REQUIRE(ld_out >= c && ld_out % 4 == 0, "layernorm: output row pitch %lld invalid", (long long)ld_out);
   SEVA_REQUIRE(rows > 0 && c > 0 && c % 4 == 0 && c <= 16 * 4 * LN_MAXV,
                "layernorm: rows=%lld c=%d unsupported", (long long)rows, c);
   hipStream_t s = (hipStream_t)stream;
@@ -449,10 +454,10 @@ int layernorm_entry(const float* x, const float* gamma, const float* beta, void*
   do {                                                                                                      \
     if (lr == 4)                                                                                            \
       hipLaunchKernelGGL((layernorm_kernel<NV, 4, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
-                         beta, (half_t*)out, rows, c, eps);                                                 \
+                         beta, (half_t*)out, rows, c, eps, ld_out);                                         \
     else                                                                                                    \
       hipLaunchKernelGGL((layernorm_kernel<NV, 1, OUT>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma,  \
-                         beta, (half_t*)out, rows, c, eps);                                                 \
+                         beta, (half_t*)out, rows, c, eps, ld_out);                                         \
   } while (0)
   if (nv <= 2) SEVA_LN_LAUNCH(2);
   else if (nv <= 5) SEVA_LN_LAUNCH(5);
@@ -471,9 +476,9 @@ extern "C" int seva_layernorm_f16(const float* x, const float* gamma, const floa
 
 // same normalisation, output as OCP e4m3 bytes (saturating): A operand of seva_gemm_fp8
 extern "C" int seva_layernorm_fp8(const float* x, const float* gamma, const float* beta,
-                                  void* out_f8, int64_t rows, int32_t c, float eps,
+                                  void* out_f8, int64_t rows, int32_t c, float eps, int64_t ld_out,
                                   seva_stream_t stream) {
-  return layernorm_entry<1>(x, gamma, beta, out_f8, rows, c, eps, stream);
+  return layernorm_entry<1>(x, gamma, beta, out_f8, rows, c, eps, stream, ld_out);
 }
 
 // fp32 output (input and output must not overlap)

@@ -37,6 +37,10 @@ CIN_PAD = 64  # conv A-operand channel granularity (one K-tile per tap)
 
 
 # --------------------------------------------------------------------------- weight packing
+def _pad128(k: int) -> int:
+    return 128 * ((k + 127) // 128)
+
+
 def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
     """[cout, cin, 3, 3] -> f16 [cout, 9*cin_pad], K ordered (ky, kx, ci); extra channels zero."""
     cout, cin = w.shape[:2]
@@ -91,8 +95,9 @@ class SevaEngine:
 
     def __init__(self, model, precision: str | None = None):
         """precision "f16" (default; the parity mode, fp16 operands / fp32 accumulation) or "fp8" (BASELINE config 5:
-        e4m3 weights AND activations on the block-scaled fp8 MFMA for every GEMM / 3x3 conv whose reduction length is a
-        multiple of 128 -- the C = 640 / 1280 levels; the C = 320 level and the small projections stay f16)."""
+        e4m3 weights AND activations on the block-scaled fp8 MFMA for the QKV / GEGLU / FF2 projections and the ResBlock 3x3
+        convs of every level; reduction lengths that are not a multiple of 128 are zero-padded when that costs <= 25 %
+        (C = 320 -> 384, 960 -> 1024); attention, the small projections and the resampling convs stay f16)."""
         import os as _os
 
         self.device = self._resolve_device(model)
@@ -143,9 +148,18 @@ class SevaEngine:
         emb_total = ctx_total = 0
 
         def q8(name, w):
-            """fp8 mode: e4m3 copy + per-row power-of-two scale bytes of an [N, K] weight whose K is a multiple of 128"""
-            if self.fp8 and w.shape[1] % 128 == 0 and w.shape[0] % 16 == 0 and w.shape[0] > 32:
-                W[name + "8"], W[name + "8e"] = ops.quantize_weight_fp8(w)
+            """fp8 mode: e4m3 copy + per-row power-of-two scale bytes of an [N, K] weight; K is zero-padded to a multiple of
+            128 (one MFMA K-tile) when that costs at most 25 % (320 -> 384: the producing LayerNorm writes into a zero-padded
+            buffer of that width)"""
+            if not (self.fp8 and w.shape[0] % 16 == 0 and w.shape[0] > 32):
+                return
+            k = w.shape[1]
+            kp = _pad128(k)
+            if kp * 4 > k * 5:
+                return
+            if kp != k:
+                w = torch.cat([w, w.new_zeros((w.shape[0], kp - k))], 1)
+            W[name + "8"], W[name + "8e"] = ops.quantize_weight_fp8(w)
 
         def pack_attn_self(pfx):
             W[pfx + ".qkv"] = torch.cat(
@@ -170,9 +184,10 @@ class SevaEngine:
             wi, bi = interleave_geglu(f16(pfx + ".net.0.proj.weight"), f32(pfx + ".net.0.proj.bias"))
             W[pfx + ".w1"], W[pfx + ".b1"] = wi, bi
             W[pfx + ".w2"], W[pfx + ".b2"] = f16(pfx + ".net.2.weight"), f32(pfx + ".net.2.bias")
-            if self.fp8 and wi.shape[1] % 128 == 0:  # both or neither: the hidden activations travel as e4m3
+            if self.fp8:  # both or neither: the hidden activations travel as e4m3
                 q8(pfx + ".w1", interleave_geglu(f32(pfx + ".net.0.proj.weight"), f32(pfx + ".net.0.proj.bias"))[0])
-                q8(pfx + ".w2", f32(pfx + ".net.2.weight"))
+                if pfx + ".w18" in W:
+                    q8(pfx + ".w2", f32(pfx + ".net.2.weight"))
 
         def pack_ln(pfx):
             W[pfx + ".g"], W[pfx + ".b"] = f32(pfx + ".weight"), f32(pfx + ".bias")
@@ -190,11 +205,11 @@ class SevaEngine:
                 W[pfx + ".conv1.b"] = f32(pfx + ".in_layers.2.bias")
                 W[pfx + ".conv2.w"] = pack_conv3x3(f32(pfx + ".out_layers.3.weight"))
                 W[pfx + ".conv2.b"] = f32(pfx + ".out_layers.3.bias")
-                if self.fp8:  # K = 9*cin ordered (ky, kx, ci): a 128-deep K-tile must not straddle taps
-                    if spec.cin % 128 == 0:
-                        q8(pfx + ".conv1.w", pack_conv3x3(f32(pfx + ".in_layers.2.weight")).float())
-                    if spec.cout % 128 == 0:
-                        q8(pfx + ".conv2.w", pack_conv3x3(f32(pfx + ".out_layers.3.weight")).float())
+                if self.fp8:  # K = 9*cin_pad ordered (ky, kx, ci): a 128-deep K-tile must not straddle taps -> channels padded
+                    for tag, key, ch in (("conv1", "in_layers.2", spec.cin), ("conv2", "out_layers.3", spec.cout)):
+                        cp = _pad128(ch)
+                        if cp * 4 <= ch * 5:
+                            q8(f"{pfx}.{tag}.w", pack_conv3x3(f32(f"{pfx}.{key}.weight"), cp).float())
                 W[pfx + ".dense.w"] = f32(pfx + ".dense_emb_layers.0.weight").reshape(2 * spec.cin, -1).contiguous()
                 W[pfx + ".dense.b"] = f32(pfx + ".dense_emb_layers.0.bias")
                 emb_w.append(f16(pfx + ".emb_layers.1.weight"))
@@ -234,11 +249,20 @@ class SevaEngine:
         self.W = W
 
     # ------------------------------------------------------------------ helpers
-    def _buf(self, name, shape, dtype):
-        return self.arena.get(name, shape, dtype)
+    def _buf(self, name, shape, dtype, zero=False):
+        key = (name, tuple(int(v) for v in shape), dtype)
+        fresh = zero and key not in self.arena.bufs
+        t = self.arena.get(name, shape, dtype)
+        if fresh:
+            t.zero_()
+        return t
 
     def _ln(self, x, pfx, rows, c, fp8=False):
-        out = self._buf("ln8", (rows, c), U8) if fp8 else self._buf("ln16", (rows, c), F16)
+        if fp8:
+            # e4m3 output, K padded to a multiple of 128: the pad columns are zeroed once (nothing ever writes them again)
+            out = self._buf("ln8", (rows, _pad128(c)), U8, zero=True)
+        else:
+            out = self._buf("ln16", (rows, c), F16)
         ops.layernorm(x, self.W[pfx + ".g"], self.W[pfx + ".b"], out)
         return out
 
@@ -295,7 +319,8 @@ class SevaEngine:
         cin, cout = spec.cin, spec.cout
         f8_1, f8_2 = pfx + ".conv1.w8" in W, pfx + ".conv2.w8" in W  # fp8 mode: the conv consumes e4m3 activations
         a16 = None if f8_1 else self._buf("gn16", (n, hw, cin), F16)
-        a8 = self._buf("gn8", (n, hw, cin), U8) if f8_1 else None
+        cin8, cout8 = _pad128(cin), _pad128(cout)  # fp8 convs see channel counts padded to a multiple of 128 (pad stays zero)
+        a8 = self._buf("gn8", (n, hw, cin8), U8, zero=True) if f8_1 else None
         # the 1x1 skip conv (cin != cout) consumes the raw input as f16: emitted by the same GroupNorm pass
         xs16 = self._buf("skip16", (n * hw, cin), F16) if cin != cout else None
         ops.groupnorm(x1, x2, W[pfx + ".in_layers.0.g"], W[pfx + ".in_layers.0.b"], a16, self.gn_ws,
@@ -304,13 +329,13 @@ class SevaEngine:
         hmid = self._buf("res_mid", (n, hw, cout), F32)
         off = self.emb_off[pfx]
         if f8_1:
-            ops.conv3x3(a8.view(n, h, w, cin), W[pfx + ".conv1.w8"], w_exp=W[pfx + ".conv1.w8e"], bias=W[pfx + ".conv1.b"],
+            ops.conv3x3(a8.view(n, h, w, cin8), W[pfx + ".conv1.w8"], w_exp=W[pfx + ".conv1.w8e"], bias=W[pfx + ".conv1.b"],
                         row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
         else:
             ops.conv3x3(a16.view(n, h, w, cin), W[pfx + ".conv1.w"], bias=W[pfx + ".conv1.b"],
                         row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
         b16 = None if f8_2 else self._buf("gn16", (n, hw, cout), F16)
-        b8 = self._buf("gn8", (n, hw, cout), U8) if f8_2 else None
+        b8 = self._buf("gn8", (n, hw, cout8), U8, zero=True) if f8_2 else None
         ops.groupnorm(hmid, None, W[pfx + ".out_layers.0.g"], W[pfx + ".out_layers.0.b"], b16, self.gn_ws,
                       eps=1e-5, silu=True, out_f8=b8)
         if cin != cout:
@@ -321,7 +346,7 @@ class SevaEngine:
             res = x1
         out = self._buf("out:" + pfx, (n, hw, cout), F32)
         if f8_2:
-            ops.conv3x3(b8.view(n, h, w, cout), W[pfx + ".conv2.w8"], w_exp=W[pfx + ".conv2.w8e"], bias=W[pfx + ".conv2.b"],
+            ops.conv3x3(b8.view(n, h, w, cout8), W[pfx + ".conv2.w8"], w_exp=W[pfx + ".conv2.w8e"], bias=W[pfx + ".conv2.b"],
                         residual=res, out_f32=out)
         else:
             ops.conv3x3(b16.view(n, h, w, cout), W[pfx + ".conv2.w"], bias=W[pfx + ".conv2.b"],

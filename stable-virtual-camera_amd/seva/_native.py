@@ -68,7 +68,7 @@ class GroupNormDesc(C.Structure):
         ("out_f16", c_void_p), ("workspace", c_void_p),
         ("n", c_int32), ("hw", c_int32), ("c1", c_int32), ("c2", c_int32),
         ("groups", c_int32), ("dense_c", c_int32), ("silu", c_int32), ("eps", c_float),
-        ("raw_f16", c_void_p), ("out_f8", c_void_p),
+        ("raw_f16", c_void_p), ("out_f8", c_void_p), ("ld_out_f8", c_int64),
     ]
 
 
@@ -83,7 +83,7 @@ SYMBOLS = {
     "seva_attention_f16": (c_int, [POINTER(AttnDesc), c_void_p]),
     "seva_groupnorm_f16": (c_int, [POINTER(GroupNormDesc), c_void_p]),
     "seva_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
-    "seva_layernorm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "seva_layernorm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int64, c_void_p]),
     "seva_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "seva_clip_preprocess_f16": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_int32, c_void_p]),

@@ -215,7 +215,9 @@ def groupnorm(
     d.dense, d.dense_w, d.dense_b = ptr(dense), ptr(dense_w), ptr(dense_b)
     d.out_f16, d.workspace = ptr(out_f16), workspace.data_ptr()
     d.out_f8 = ptr(out_f8)
-    assert out_f8 is None or (out_f8.dtype == U8 and out_f8.is_contiguous() and out_f8.numel() == n * hw * (c1 + c2))
+    if out_f8 is not None:  # [n, hw, >= c1 + c2] e4m3 bytes; a wider last dim = channel padding of an fp8 conv (pad bytes untouched)
+        assert out_f8.dtype == U8 and out_f8.is_contiguous() and out_f8.shape[:2] == (n, hw) and out_f8.shape[2] >= c1 + c2
+        d.ld_out_f8 = out_f8.shape[2]
     d.n, d.hw, d.c1, d.c2, d.groups = n, hw, c1, c2, groups
     d.dense_c = dense.shape[-1] if dense is not None else 0
     d.silu, d.eps = 1 if silu else 0, eps
@@ -237,9 +239,10 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_f16:
                                         out_f16.data_ptr(), rows, c, eps, stream_ptr(x.device)),
               "seva_layernorm_f32")
         return
-    if out_f16.dtype == U8:
+    if out_f16.dtype == U8:  # e4m3: the output may be wider than c (K padded to a multiple of 128; pad bytes stay as they are)
+        assert out_f16.dim() == 2 and out_f16.stride(1) == 1 and out_f16.shape[0] == rows
         check(_lib().seva_layernorm_fp8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                        out_f16.data_ptr(), rows, c, eps, stream_ptr(x.device)),
+                                        out_f16.data_ptr(), rows, c, eps, out_f16.stride(0), stream_ptr(x.device)),
               "seva_layernorm_fp8")
         return
     assert out_f16.dtype == F16

@@ -150,13 +150,16 @@ def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, s
     if out_f16 is not None:
         out_f16.copy_(y.half())
     if out_f8 is not None:
-        out_f8.copy_(to_fp8(y))
+        out_f8[..., : y.shape[-1]].copy_(to_fp8(y))
 
 
 def layernorm(x, gamma, beta, out_f16, eps=1e-5):
     c = x.shape[-1]
     y = F.layer_norm(x.reshape(-1, c), (c,), gamma, beta, eps)
-    out_f16.view(-1, c).copy_(to_fp8(y) if out_f16.dtype == U8 else (y if out_f16.dtype == F32 else y.half()))
+    if out_f16.dtype == U8:
+        out_f16[:, :c].copy_(to_fp8(y))  # pad columns (K padded to a multiple of 128) untouched
+    else:
+        out_f16.view(-1, c).copy_(y if out_f16.dtype == F32 else y.half())
 
 
 def clip_preprocess(x, patches_f16, mean, std, *, out_size=224, patch=14, antialias=True):

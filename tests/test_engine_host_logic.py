@@ -380,8 +380,10 @@ def test_fp8_engine_orchestration(patched):
     q = [k for k in eng.W if k.endswith("8e")]
     assert any(".qkv8e" in k for k in q) and any(".w18e" in k for k in q) and any(".w28e" in k for k in q)
     assert any(".conv1.w8e" in k for k in q) and any(".conv2.w8e" in k for k in q)
-    # the C = 64 level has no 128-deep reduction: stays f16
+    # the C = 64 level would need its reductions padded 64 -> 128 (2x): stays f16; C = 320-style paddings (<= 25 %) are taken
     assert not any(k.startswith("input_blocks.1.") and k.endswith("8e") for k in q)
+    from seva._engine import _pad128
+    assert (_pad128(320), _pad128(960), _pad128(640)) == (384, 1024, 640)
     T, h, w = 2, 8, 8
     g = torch.Generator().manual_seed(3)
     n = 2 * T

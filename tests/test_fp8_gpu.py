@@ -181,3 +181,44 @@ def test_fp8_network_accuracy_is_reported(dev):
     nq = sum(1 for k in net.engine().W if k.endswith("8e"))
     print(f"\n1.3B forward (config 1) vs reference: f16 mode rel-L2 {e16:.3e}; fp8 mode rel-L2 {e8:.3e} ({nq} e4m3 weight tensors)")
     assert e16 < 1e-3 and 1e-3 < e8 < 0.2 and nq > 100
+
+
+def test_fp8_reduction_padding_320_to_384(dev):
+    """C = 320 level in fp8 mode: the reduction length is zero-padded to 384 (one more 128-deep MFMA K-tile instead of 2.5).
+    LayerNorm writes its 320 columns into a zero-initialised [rows, 384] e4m3 buffer; GroupNorm writes 320 channels at pixel
+    pitch 384; weights carry 64 zero columns / channels per tap.  Results equal the unpadded computation exactly."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    rows, c, kp, N = 777, 320, 384, 960
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(rows, c, generator=g) * 2).to(dev)
+    gm, bt = (1 + 0.1 * torch.randn(c, generator=g)).to(dev), (0.1 * torch.randn(c, generator=g)).to(dev)
+    a8 = torch.zeros((rows, kp), device=dev, dtype=U8)
+    ops.layernorm(x, gm, bt, a8)
+    assert int(a8[:, c:].max()) == 0  # pad columns untouched
+    _close_fp8(a8[:, :c].contiguous(), F.layer_norm(x, (c,), gm, bt, 1e-5))
+    w = _ints((N, c), -3, 3, dev, 22)
+    wp = torch.cat([w, torch.zeros((N, kp - c), device=dev)], 1)
+    w8, wexp, _ = _wq(wp, dev, 23)
+    o32 = torch.full((rows, N), float("nan"), device=dev)
+    ops.gemm(a8, w8, w_exp=wexp, out_f32=o32)
+    e = wexp.float() - 127.0
+    ref = a8[:, :c].contiguous().view(torch.float8_e4m3fn).float() @ (w * torch.exp2(e)[:, None]).T
+    assert torch.allclose(o32, ref, rtol=1e-6, atol=1e-4)  # (activations are not integers here: fp32 summation order)
+    # conv: 320 channels in a 384-channel e4m3 image
+    n, ih, iw, cout = 2, 9, 7, 64
+    xi = _ints((n, c, ih, iw), -3, 3, dev, 24)
+    wc = _ints((cout, c, 3, 3), -2, 2, dev, 25)
+    img = torch.zeros((n, ih, iw, kp), device=dev, dtype=U8)
+    img[..., :c] = _f8(xi.permute(0, 2, 3, 1).contiguous())
+    wc8 = _f8(pack_conv3x3(wc, kp).float())
+    out = torch.full((n, ih * iw, cout), float("nan"), device=dev)
+    ops.conv3x3(img, wc8, w_exp=torch.full((cout,), 127, device=dev, dtype=U8), out_f32=out)
+    assert torch.equal(out.view(n, ih, iw, cout).permute(0, 3, 1, 2), F.conv2d(xi, wc, None, padding=1))
+    # GroupNorm with pixel pitch 384
+    xg = (torch.randn(n, ih * iw, c, generator=g) + 0.5).to(dev)
+    ws = ops.groupnorm_workspace(n, dev)
+    o8 = torch.zeros((n, ih * iw, kp), device=dev, dtype=U8)
+    ops.groupnorm(xg, None, gm, bt, None, ws, silu=True, out_f8=o8)
+    assert int(o8[..., c:].max()) == 0
+    _close_fp8(o8[..., :c].contiguous(), F.silu(F.group_norm(xg.permute(0, 2, 1), 32, gm, bt, 1e-5)).permute(0, 2, 1))
