@@ -96,8 +96,8 @@ class SevaEngine:
     def __init__(self, model, precision: str | None = None):
         """precision "f16" (default; the parity mode, fp16 operands / fp32 accumulation) or "fp8" (BASELINE config 5:
         e4m3 weights AND activations on the block-scaled fp8 MFMA for the QKV / GEGLU / FF2 projections and the ResBlock 3x3
-        convs of every level; reduction lengths that are not a multiple of 128 are zero-padded when that costs <= 25 %
-        (C = 320 -> 384, 960 -> 1024); attention, the small projections and the resampling convs stay f16)."""
+        convs whose reduction length is a multiple of 128 -- the C = 640 / 1280 levels; the C = 320 level (opt-in through
+        zero-padding, SEVA_FP8_PAD=1: no gain, see below), attention, the small projections and the resampling convs stay f16)."""
         import os as _os
 
         self.device = self._resolve_device(model)
@@ -105,6 +105,10 @@ class SevaEngine:
         if self.precision not in ("f16", "fp8"):
             raise ValueError(f"unknown precision {self.precision!r} (f16 | fp8)")
         self.fp8 = self.precision == "fp8"
+        # fp8 mode only: also take reductions that need zero-padding to a multiple of 128 (C = 320 -> 384, 960 -> 1024).  Off by
+        # default -- measured (profiles/r02_bench_T21_fp8_pad320.json): the C = 320 level then leaves the fused f16 feed-forward
+        # for the two-kernel fp8 path, the step stays at 86.1 ms and the error doubles (rel-L2 2.9e-2 -> 5.2e-2).
+        self.fp8_pad = _os.environ.get("SEVA_FP8_PAD", "0") == "1"
         self.ff_fused = _os.environ.get("SEVA_FF_FUSED", "1") != "0"  # 0: two-kernel GEGLU + FF2 everywhere (A/B runs)
         self.p = model.params
         self.layout: Layout = model._layout
@@ -155,7 +159,7 @@ class SevaEngine:
                 return
             k = w.shape[1]
             kp = _pad128(k)
-            if kp * 4 > k * 5:
+            if kp != k and (not self.fp8_pad or kp * 4 > k * 5):
                 return
             if kp != k:
                 w = torch.cat([w, w.new_zeros((w.shape[0], kp - k))], 1)
@@ -208,7 +212,7 @@ class SevaEngine:
                 if self.fp8:  # K = 9*cin_pad ordered (ky, kx, ci): a 128-deep K-tile must not straddle taps -> channels padded
                     for tag, key, ch in (("conv1", "in_layers.2", spec.cin), ("conv2", "out_layers.3", spec.cout)):
                         cp = _pad128(ch)
-                        if cp * 4 <= ch * 5:
+                        if cp == ch or (self.fp8_pad and cp * 4 <= ch * 5):
                             q8(f"{pfx}.{tag}.w", pack_conv3x3(f32(f"{pfx}.{key}.weight"), cp).float())
                 W[pfx + ".dense.w"] = f32(pfx + ".dense_emb_layers.0.weight").reshape(2 * spec.cin, -1).contiguous()
                 W[pfx + ".dense.b"] = f32(pfx + ".dense_emb_layers.0.bias")
