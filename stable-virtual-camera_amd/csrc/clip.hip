@@ -8,6 +8,8 @@
 //     fp32 VALU math out of an f16 K/V image in LDS (no MFMA: 21 MFLOP per (frame, head)).
 #include "seva_common.h"
 
+#include <atomic>
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -210,10 +212,13 @@ extern "C" int seva_attention_small_f16(const void* q, const void* k, const void
   const int DP = head_dim + 2, LP = (L + 63) & ~63;
   const size_t lds = (size_t)2 * L * DP * 2 + 4 + (size_t)SA_WAVES * (LP + head_dim) * 4;
   SEVA_REQUIRE(lds <= 160 * 1024, "attention_small: L=%d d=%d needs %zu bytes of LDS (max 160 KiB)", L, head_dim, lds);
-  static bool attr = false;  // one device per process (one process per GPU)
-  if (!attr) {
+  static std::atomic<uint64_t> attr_devs{0};  // the dynamic-LDS attribute is per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t dev_bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
     (void)hipFuncSetAttribute((const void*)attn_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
+    attr_devs.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   SmallAttnArgs a{};
   a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.out = (half_t*)out;
