@@ -21,8 +21,10 @@ in plan order and keeps its own windows'.  The per-step device noise (`randn_lik
 generator owned by the window (seed = scene seed, window index), so a window's result does not depend on which rank
 runs it or on what ran before it: a sharded run equals the sequential run bit for bit (tested on gloo, world size 2).
 
-The CLIP image conditioner is not part of this path: the caller supplies the 1024-d token
-(`clip_token`, or `clip_fn(window_source_ids) -> (1024,)` to vary it per window like eval.py:1248).
+CLIP token: `clip_token` (one 1024-d token for every window), `clip_fn(window_source_ids) -> (1024,)`, or -- the reference's
+own rule (eval.py:1248: mean CLIP embedding of the window's conditioning views) -- `conditioner=` + `input_rgb=` with
+`handoff="rgb"` and an `ae`: the anchors are then decoded once after pass 1, every window's token is
+`conditioner(rgb of its conditioning frames).mean(0)` and the anchors re-enter pass 2 through `ae.encode`, as in the reference.
 """
 
 from __future__ import annotations
@@ -169,7 +171,8 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
                    camera_scale: float = 2.0, seed: int = 23, chunk_strategy: str = "interp",
                    first_pass_strategy: str = "gt", device=None, group=None, ae=None, handoff: str = "latent",
                    plan: TrajectoryPlan | None = None, timers: dict | None = None,
-                   sampler_hook: Callable | None = None) -> dict:
+                   sampler_hook: Callable | None = None, conditioner: Callable | None = None,
+                   input_rgb: torch.Tensor | None = None) -> dict:
     """Generate every non-input frame of a trajectory.  `denoise_net(x, t, cond, num_frames=T)` is the network call
     (`SGMWrapper(model)`); `input_latents` (n_in,4,h,w) are the VAE-encoded input views (x 0.18215), frame ids
     `input_ids` index `c2ws` (n,4,4) / `Ks` (n,3,3).  Returns, on rank 0, {"latents": (n,4,h,w) in frame order,
@@ -178,8 +181,19 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
     device = torch.device(device) if device is not None else input_latents.device
     h, w = input_latents.shape[-2:]
     plan = plan or plan_trajectory(c2ws, input_ids, T, chunk_strategy, first_pass_strategy)
-    tok = (lambda ids: clip_token) if clip_fn is None else clip_fn
-    assert clip_fn is not None or clip_token is not None, "a CLIP token (or clip_fn) is required"
+    rgb_of: dict = {}
+    if conditioner is not None:
+        # the reference's rule (eval.py:1248): token of a window = mean CLIP embedding of its conditioning views' RGB
+        assert input_rgb is not None and ae is not None and handoff == "rgb", \
+            "conditioner= needs input_rgb=, ae= and handoff='rgb' (anchor RGB comes from the VAE decode between the passes)"
+        for i, fid in enumerate(plan.input_ids):
+            rgb_of[fid] = input_rgb[i].to(device)
+
+        def tok(ids):
+            return conditioner(torch.stack([rgb_of[f] for f in ids])).mean(0)
+    else:
+        tok = (lambda ids: clip_token) if clip_fn is None else clip_fn
+        assert clip_fn is not None or clip_token is not None, "a CLIP token (clip_token / clip_fn / conditioner) is required"
 
     # initial noise: ONE CPU stream, seeded once per scene, drawn in plan order for EVERY window (eval.py:1294-1295,1450)
     g0 = torch.Generator(device="cpu")
@@ -201,9 +215,13 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
             import time
             timers[name] = time.perf_counter()
 
-    def handoff_latent(z):  # (k,4,h,w) generated latents -> what the next window conditions on
+    def handoff_latent(z, fids=None):  # (k,4,h,w) generated latents -> what the next window conditions on
         if handoff == "rgb" and ae is not None:
-            return ae.encode(ae.decode(z))
+            rgb = ae.decode(z)
+            if conditioner is not None and fids is not None:
+                for fid, img in zip(fids, rgb):
+                    rgb_of[fid] = img
+            return ae.encode(rgb)
         return z
 
     mark("start")
@@ -216,7 +234,7 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
         win = plan.pass1[i]
         z = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index], step_seed=step_seed(win),
                        clip_token=tok(win.source_ids), **common)
-        zt = handoff_latent(z[win.target_slots])
+        zt = handoff_latent(z[win.target_slots], win.target_ids)
         for fid, lat in zip(win.target_ids, zt):
             latents_of[fid] = lat  # a dependent strategy's next window on this rank may read it
             got_ids.append(fid)
@@ -235,6 +253,10 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
     for r in range(world):
         for j, fid in enumerate(owner_ids[r]):
             latents_of[fid] = parts[r][j]
+    if conditioner is not None:  # ranks that did not generate an anchor need its RGB for the CLIP token: decode locally (1.66 MB of
+        for fid in plan.anchor_ids:  # latents travelled, not 40 MB of RGB)
+            if fid not in rgb_of:
+                rgb_of[fid] = ae.decode(latents_of[fid][None])[0]
     mark("exchange")
     # ------------------------------------------------------------------ pass 2: independent windows, sharded
     mine2 = shard_windows(len(plan.pass2), rank, world)

@@ -122,3 +122,38 @@ def test_two_rank_sharded_trajectory_equals_sequential(first_pass, monkeypatch):
     got = torch.from_numpy(res[0][1])
     assert torch.equal(got, ref), float((got - ref).abs().max())
     assert res[0][2] == ["exchange", "gather", "pass1", "pass2", "start"]
+
+
+def test_reference_style_rgb_handoff_and_per_window_clip_token(monkeypatch):
+    """handoff='rgb' + conditioner=: anchors go decode -> encode between the passes and every window's CLIP token is the mean
+    embedding of ITS conditioning views (reference eval.py:1248, 1820-1829), here with linear stand-ins for the VAE / CLIP."""
+    from seva import pipeline
+    _patch_cpu(monkeypatch)
+    c2ws, Ks, lat, _ = _scene(n=50)
+
+    class FakeAE:
+        def decode(self, z):  # (k,4,h,w) -> (k,3,h,w)
+            return torch.tanh(z[:, :3] * 0.5 + 0.1 * z[:, 3:4])
+
+        def encode(self, x):
+            return torch.cat([x * 1.5, x.mean(1, keepdim=True)], 1)
+
+    seen = []
+
+    def fake_clip(imgs):  # (k,3,h,w) -> (k,1024)
+        seen.append(imgs.shape[0])
+        g = torch.Generator().manual_seed(0)
+        proj = torch.randn(3 * 8 * 8, 1024, generator=g) * 0.05
+        return imgs.reshape(imgs.shape[0], -1) @ proj
+
+    rgb_in = FakeAE().decode(lat)
+    res = pipeline.run_trajectory(_fake_net, lat, c2ws, Ks, [0], T=21, num_steps=2, seed=5, device="cpu", ae=FakeAE(),
+                                  handoff="rgb", conditioner=fake_clip, input_rgb=rgb_in)
+    plan = res["plan"]
+    assert res["latents"].shape == (50, 4, 8, 8) and torch.isfinite(res["latents"]).all() and "rgb" in res
+    # one conditioner call per window, over exactly that window's conditioning views
+    assert seen == [len(w.source_ids) for w in plan.pass1 + plan.pass2]
+    # anchors went through the RGB round trip: what pass 2 conditioned on is encode(decode(.)), whose 4th channel is the
+    # mean of the first three divided by 1.5 under this stand-in
+    a = plan.anchor_ids[0]
+    assert torch.allclose(res["latents"][a][3], res["latents"][a][:3].mean(0) / 1.5, atol=1e-6)
