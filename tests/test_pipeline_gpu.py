@@ -1,0 +1,51 @@
+"""Two-pass trajectory driver (`seva.pipeline`, BASELINE config 4) on the HIP path, one GPU: a 50-view orbit through the tiny
+UNet -- every frame generated exactly once, the input frame untouched, deterministic, and window results independent of the
+execution order (what makes sharding over ranks a pure scheduling decision; the 2-rank run itself is tested on gloo)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from seva import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+def test_trajectory_on_gpu_tiny(dev):
+    from test_model_gpu import _build
+    from seva import pipeline
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+    net, _ = _build("tiny", dev)
+    n, hw, T = 50, 16, 21
+    c2ws, Ks = synth.orbit_c2w(n), synth.default_K(n)
+    g = torch.Generator().manual_seed(3)
+    lat = (torch.randn(1, 4, hw, hw, generator=g) * 0.9).to(dev)
+    tok = torch.randn(1024, generator=g)
+    tok = (tok / tok.norm()).to(dev)
+    wrap = SGMWrapper(net)
+    plan = pipeline.plan_trajectory(c2ws, [0], T=T)
+    assert len(plan.pass1) >= 1 and len(plan.pass2) >= 2
+    kw = dict(clip_token=tok, T=T, num_steps=3, device=dev, plan=plan)
+    with torch.no_grad():
+        a = pipeline.run_trajectory(wrap, lat, c2ws, Ks, [0], **kw)
+        b = pipeline.run_trajectory(wrap, lat, c2ws, Ks, [0], **kw)
+    assert a["latents"].shape == (n, 4, hw, hw) and torch.isfinite(a["latents"]).all()
+    assert torch.equal(a["latents"], b["latents"])
+    assert torch.equal(a["latents"][0], lat[0])
+    # a pass-2 window run on its own (as another rank would) reproduces its frames bit for bit
+    win = plan.pass2[-1]
+    latents_of = {0: lat[0], **{f: a["latents"][f] for f in plan.anchor_ids}}
+    g0 = torch.Generator().manual_seed(23)
+    noises = [torch.randn((T, 4, hw, hw), generator=g0) for _ in range(len(plan.pass1) + len(plan.pass2))]
+    with torch.no_grad():
+        z = pipeline.run_window(win, latents_of, wrap, c2ws, Ks, hw=(hw, hw), num_steps=3, cfg=2.0, cfg_min=1.2, guider=1,
+                                camera_scale=2.0, noise=noises[win.global_index],
+                                step_seed=(23 * 1000003 + 7919 * (win.global_index + 1)) & 0x7FFFFFFFFFFF, clip_token=tok, device=dev)
+    for fid, slot in zip(win.target_ids, win.target_slots):
+        assert torch.equal(z[slot], a["latents"][fid])
