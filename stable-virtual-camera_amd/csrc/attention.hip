@@ -394,7 +394,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 // instruction stream (the three-waves-per-SIMD kernel above relies on the hardware interleaving
 // separate waves, which barrier and wait stalls defeat about 40 % of the time).  Same LDS ring,
 // operand layouts, online-softmax arithmetic and rounding as attn_kernel<4, 64, true, false, true>.
-template <int KT>
+// SCHED (knob attn_two = 2): the same arithmetic, re-ordered so that each chain's exp / pack VALU work sits in ONE basic
+// block with the OTHER chain's MFMAs, and pinned there with sched_group_barrier (1 LDS read + 1 MFMA + 4 transcendental + 6
+// VALU per group).  The wave-uniform rescale branches stay outside those blocks:
+//   [QK(A), max(A)] -rescale A?- [QK(B) || exp(A), max(B)] -rescale B?- [PV(A) || exp(B)] [PV(B)]
+template <int KT, bool SCHED = false>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   constexpr int NW = 4, QB = 2, KB = KT / 32;
   __shared__ __attribute__((aligned(16))) char smem[3 * 2 * KT * 128];
@@ -496,7 +500,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
         }
       }
     };
-    auto softmax = [&](int c) {
+    // softmax split in two: the part that may branch (mask, running max, rare rescale) and the branch-free exp / pack part
+    auto rescale_part = [&](int c) {
       if (MASKED) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -527,6 +532,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[c][kb][r] -= delta;
       }
+    };
+    auto exp_part = [&](int c) {
       const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
       float ls0 = 0.f, ls1 = 0.f;  // two partial sums: shorter dependent dot2 chains
 #pragma unroll
@@ -546,6 +553,10 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
         }
       l_run[c] += ls0 + ls1;
     };
+    auto softmax = [&](int c) {
+      rescale_part(c);
+      exp_part(c);
+    };
     auto pv = [&](int c) {
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -562,12 +573,51 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
             acc_o[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c][kb][s2], acc_o[c][db], 0, 0, 0);
           }
     };
-    qk(0);
-    qk(1);
-    softmax(0);
-    pv(0);
-    softmax(1);
-    pv(1);
+    if constexpr (SCHED) {
+      constexpr int NM = 4 * KB;  // MFMAs of one chain's QK (and of half of its PV)
+      qk(0);
+      rescale_part(0);
+      // ---- block 1: QK(B) MFMAs with exp / pack of chain A in their shadow ----
+      __builtin_amdgcn_sched_barrier(0);
+      qk(1);
+      exp_part(0);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (the MFMA's K fragment)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);  // 4 x v_exp_f32
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // cvt_pkrtz / dot2 / accumulator splats
+      }
+      // pin chain A's packed probabilities HERE: they are first used in block 2, and LLVM's IR-level sinking would otherwise
+      // move the whole exp / pack computation down to that use (out of the MFMAs' shadow)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(pf[0][kb][s2]));
+      asm volatile("" : "+v"(l_run[0]));
+      __builtin_amdgcn_sched_barrier(0);
+      rescale_part(1);
+      // ---- block 2: PV(A) MFMAs with exp / pack of chain B in their shadow, then PV(B) ----
+      __builtin_amdgcn_sched_barrier(0);
+      pv(0);
+      exp_part(1);
+#pragma unroll
+      for (int i = 0; i < 2 * NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the tr-read pair of the MFMA's V fragment
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      pv(1);
+    } else {
+      qk(0);
+      qk(1);
+      softmax(0);
+      pv(0);
+      softmax(1);
+      pv(1);
+    }
     if (more2) wait_vm<G>();
     else wait_vm<0>();
     __syncthreads();
@@ -689,7 +739,7 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   // (27.5 vs 27.3 ms/step): hipcc issues both chains' Q*K groups up front, the wave-uniform rescale
   // branches split the tile into basic blocks it does not schedule across, and 38 + 32 register moves per
   // tile appear at 251 VGPRs.  Kept, bit-compatible and tested, as the base for a hand-scheduled version.
-  if (pre && use_tr && !a.dbg && d->lq >= 512 && g_seva_knobs.attn_two == 1) {
+  if (pre && use_tr && !a.dbg && d->lq >= 512 && (g_seva_knobs.attn_two == 1 || g_seva_knobs.attn_two == 2)) {
     AttnArgs args = a;
     args.qblocks = (a.lq + 255) / 256;
     const int64_t nb = batch * a.heads * args.qblocks;
@@ -697,7 +747,8 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
       seva_set_error("attention: bad grid %lld", (long long)nb);
       return SEVA_ERR_ARG;
     }
-    hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
+    if (g_seva_knobs.attn_two == 2) hipLaunchKernelGGL((attn2_kernel<64, true>), dim3((unsigned)nb), dim3(256), 0, s, args);
+    else hipLaunchKernelGGL((attn2_kernel<64, false>), dim3((unsigned)nb), dim3(256), 0, s, args);
     return seva_check_launch("attn2_kernel");
   }
   return launch<4, 64>(a, batch, s, use_tr, pre);
