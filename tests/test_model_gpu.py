@@ -431,7 +431,7 @@ def test_vae_encode_576_frame_and_chunking(dev):
 
 
 # ------------------------------------------------------------------ whole-step hipGraph (seva/_stepgraph.py)
-def _loop(net, dev, T, hw, steps, eps, guider=None, inference=False):
+def _loop(net, dev, T, hw, steps, eps, guider=None, inference=False, scale=2.0):
     from seva import sampling as S
     from seva import synthetic as synth
     from seva.model import SGMWrapper
@@ -447,9 +447,11 @@ def _loop(net, dev, T, hw, steps, eps, guider=None, inference=False):
     def run():
         cond = {k: v.to(dev) for k, v in sc["cond"].items()}
         uc = {k: v.to(dev) for k, v in sc["uc"].items()}
-        return sampler(lambda x, s, c: den(wrap, x, s, c, num_frames=T), sc["noise"].to(dev), scale=2.0,
-                       cond=cond, uc=uc, verbose=False, c2w=sc["c2w"].to(dev), K=sc["K"].to(dev),
-                       input_frame_mask=sc["input_frame_mask"].to(dev))
+        # VanillaCFG takes no camera arguments (reference eval.py passes them to the multiview guiders only)
+        kw = {} if isinstance(sampler.guider, S.VanillaCFG) and not isinstance(sampler.guider, S.MultiviewCFG) else dict(
+            c2w=sc["c2w"].to(dev), K=sc["K"].to(dev), input_frame_mask=sc["input_frame_mask"].to(dev))
+        return sampler(lambda x, s, c: den(wrap, x, s, c, num_frames=T), sc["noise"].to(dev), scale=scale,
+                       cond=cond, uc=uc, verbose=False, **kw)
 
     if inference:
         with torch.inference_mode():
@@ -467,8 +469,6 @@ def test_whole_step_graph_is_bit_identical_to_eager(dev, tiny, guider_kind, monk
     g = torch.Generator().manual_seed(5)
     eps = [torch.randn(T, 4, hw, hw, generator=g) for _ in range(steps)]
     mk = lambda: [S.VanillaCFG(), S.MultiviewCFG(1.2), S.MultiviewTemporalCFG(T, 1.2)][guider_kind]  # noqa: E731
-    if guider_kind == 0:
-        pytest.skip("VanillaCFG takes no camera kwargs (reference eval.py passes them only to guiders 1/2)")
     monkeypatch.setenv("SEVA_STEPGRAPH", "0")
     monkeypatch.setenv("SEVA_HIPGRAPH", "0")
     ref, s0 = _loop(net, dev, T, hw, steps, eps, mk())
