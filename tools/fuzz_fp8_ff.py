@@ -2,7 +2,8 @@
 """Randomised checks of the round-2 kernels (one process, seeded):
   * seva_gemm_fp8 (plain / conv) on integer data with random power-of-two channel scales: BIT-EXACT vs torch;
   * seva_ff_fused_f16 (8-wave and 4-wave, with and without the LayerNorm prologue) vs the two-kernel GEGLU + FF2 path:
-    BIT-IDENTICAL (same f16 rounding of the hidden tensor, same fp32 accumulation order).
+    the 4-wave kernel BIT-IDENTICAL (same f16 rounding of the hidden tensor, same fp32 operation order), the 8-wave kernel
+    within 2e-5 rel-L2 (its stage-1 accumulators start from the bias: one fp32 add in a different place).
 usage: python tools/fuzz_fp8_ff.py [seed] [cases]"""
 import os, random, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stable-virtual-camera_amd"))
@@ -78,10 +79,11 @@ for case in range(cases):
         ops.gemm(a, wi, bias=bi, out_f16=hid, geglu=True)
         two = torch.empty((M, C), device=dev)
         ops.gemm(hid, w2, bias=b2, residual=res, out_f32=two)
-        ok = torch.equal(got, two)
-        desc = f"ff C={C} M={M} variant={variant} res={res is not None}"
-        if not ok:
-            desc += f" rel {float((got - two).norm() / two.norm()):.2e}"
+        # 4-wave kernel: same operation order as the pair -> bit-identical.  8-wave kernel: the GEGLU bias is the accumulators'
+        # initial value (added first instead of last) -> equal up to fp32 rounding of that one add
+        rel = float((got - two).norm() / two.norm())
+        ok = torch.equal(got, two) if variant == 4 else rel < 2e-5
+        desc = f"ff C={C} M={M} variant={variant} res={res is not None} rel {rel:.2e}"
     if not ok:
         bad += 1
         print("MISMATCH", case, desc, flush=True)
