@@ -610,7 +610,7 @@ def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res, variant, knobs):
     torch.cuda.synchronize()
     assert torch.isfinite(o32).all()
     e_two, e_ref = rel_l2(o32, two), rel_l2(o32, ref)
-    assert e_two < 2e-5, e_two
+    assert e_two < (1e-4 if variant == 8 else 1e-12), e_two  # 4-wave: bit-identical; 8-wave: bias-first accumulation, f16 ties
     assert e_ref < 1e-3, e_ref
     assert torch.equal(o16, o32.half())
     o16b = torch.full((M, C), float("nan"), device=dev, dtype=torch.float16)  # f16-only output (time-mix tail)
