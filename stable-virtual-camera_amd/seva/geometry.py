@@ -93,15 +93,18 @@ def get_plucker_coordinates(extrinsics_src, extrinsics, intrinsics=None, fov_rad
         assert torch.all(pp >= 0) and torch.all(pp <= 1), (
             "Intrinsics should be expressed in resolution-independent normalized image coordinates."
         )
-    c2w_src = torch.linalg.inv(extrinsics_src)
-    rel = torch.einsum("vnm,vmp->vnp", extrinsics, c2w_src[None].repeat(V, 1, 1))
     intrinsics[:, :2] *= extrinsics.new_tensor([w, h]).view(1, -1, 1)  # mutates the argument, like the reference
-    K = intrinsics.float()
+    # The per-view linear algebra (V + 1 inverses of 4x4 / 3x3 matrices) runs on the HOST whatever device the inputs live on:
+    # batched GPU inverses of 21 tiny matrices go through the solver library and cost tens of milliseconds per window
+    # (measured: cond assembly 22-66 ms, most of it here); on the CPU they cost microseconds.
+    ext_h, src_h = extrinsics.detach().float().cpu(), extrinsics_src.detach().float().cpu()
+    c2w_src = torch.linalg.inv(src_h)
+    rel = torch.einsum("vnm,vmp->vnp", ext_h, c2w_src[None].repeat(V, 1, 1))
+    K = intrinsics.detach().float().cpu()
     if K.shape[0] == 1 and V > 1:
         K = K.repeat(V, 1, 1)
-    # the two small per-view inverses stay on the host side of the boundary (V x 3x3 and V x 4x4)
     kinv = torch.linalg.inv(K)
-    pose_inv = torch.linalg.inv(to_hom_pose(rel[:, :3, :].float()))[:, :3, :4]
+    pose_inv = torch.linalg.inv(to_hom_pose(rel[:, :3, :]))[:, :3, :4]
     dev = _compute_device(extrinsics, intrinsics)
     out = torch.empty((V, 6, h, w), dtype=torch.float32, device=dev)
     ops.plucker(kinv.to(dev).contiguous(), pose_inv.to(dev).contiguous(), out)
