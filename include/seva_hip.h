@@ -82,6 +82,13 @@ typedef struct seva_gemm_desc {
   const void* w_exp;     /* uint8 [N]: E8M0 scale byte 127 + e[n]; weight row n holds e4m3(w[n] * 2^-e[n]) */
   void* out_f8;          /* GEGLU epilogue: e4m3 [M][ldo8] (saturating), the next fp8 GEMM's A operand; or NULL */
   int64_t ldo8;
+  /* optional (NULL = off): GroupNorm statistics of out_f32, emitted by the epilogue while the values are in registers,
+   * so that the GroupNorm consuming this tensor (seva_groupnorm_desc.stats1 / stats2) needs no statistics pass over it.
+   * float [ceil(M / 64)][2][N]: for every block of 64 consecutive output rows (aligned to multiples of 64 rows of the
+   * whole tensor) and every output channel, the sum ([..][0][n]) and the sum of squares ([..][1][n]) of the fp32 values
+   * stored (after bias / row_add / residual); rows >= M contribute nothing.  Per channel, so any grouping or channel
+   * concatenation can be formed by the consumer.  Plain epilogue with out_f32 and N >= 128 only; forces 128-row tiles. */
+  float* ch_stats;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 /* BASELINE config 5 ("fp8 weights, CDNA4 fp8 MFMA"): the same operator with BOTH operands in OCP e4m3 (a: [M][lda]
@@ -180,6 +187,12 @@ typedef struct seva_groupnorm_desc {
   void* out_f8;
   int64_t ld_out_f8; /* pixel pitch of out_f8 in bytes (>= c1 + c2; 0 = c1 + c2): lets a 320-channel tensor feed an fp8 conv whose
                       * channel count is padded to a multiple of 128 (pad bytes are never written: keep them zero) */
+  /* optional: per-channel partial statistics of x1 / x2 as written by the kernel that produced them
+   * (seva_gemm_desc.ch_stats: [n * hw / 64][2][c]).  When given for every source, the statistics pass over the fp32
+   * tensors is skipped (x1 / x2 are then read once, by the apply pass).  Requires hw % 64 == 0 (a 64-row block then
+   * belongs to one sample and a sample's statistics stay bitwise independent of the batch). */
+  const float* stats1;
+  const float* stats2;
 } seva_groupnorm_desc;
 int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
 

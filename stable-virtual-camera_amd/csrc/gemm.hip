@@ -65,6 +65,18 @@ __device__ __forceinline__ f32x4 mfma_f8(int j, half8_t w_lo, half8_t w_hi, half
   }
 }
 
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror 8, 4, 2, 1: a fixed association)
+__device__ __forceinline__ float row16_sum(float v) {
+#define SEVA_ROR_ADD(N)                                                                                              \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false))
+  SEVA_ROR_ADD(8);
+  SEVA_ROR_ADD(4);
+  SEVA_ROR_ADD(2);
+  SEVA_ROR_ADD(1);
+#undef SEVA_ROR_ADD
+  return v;
+}
+
 template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int dbg = DBGK ? p.dbg : 0;
@@ -98,6 +110,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   // FP8: weight row (relative to n0 + wn*WN) that MFMA row `r` of block j reads (the fragment-read row of b_frag_off)
   auto wrow_of = [](int j, int r) { return j < NJP ? 32 * (j >> 1) + 4 * (j & 1) + 8 * (r >> 2) + (r & 3) : 16 * j + r; };
   constexpr int NSC = (NJ + 3) / 4;  // packed scale words per lane
+  // instantiations that can emit GroupNorm statistics (GemmArgs::ch_stats): a wave owns a 64-row block of the f32 output
+  constexpr bool STATS_OK = EPI == 0 && !PAIRED && !ASTAT && !DBGK && WM == 64 && NJ >= 4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [A buf0][A buf1][B buf0][B buf1]
@@ -588,6 +602,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         fj[j] = (int)f;
         bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      // GroupNorm statistics of the tensor being written (ch_stats): the wave's 64 rows x WN channels are summed here, while
+      // the values are in registers, so that the consuming GroupNorm needs no statistics pass over the fp32 tensor.
+      // Per channel (not per group: any grouping / channel concatenation can be formed later) and per 64-ROW BLOCK of the
+      // output: blocks are aligned to multiples of 64 rows of the whole tensor, so for images of hw % 64 == 0 pixels a block
+      // never straddles two samples and a sample's partial sums are bitwise independent of what it is batched with.
+      // It runs as a second pass AFTER the stores, one 16-channel block at a time (8 live sums), over the accumulator
+      // registers, which the store pass leaves holding the final values (accumulating all 2 x NJ x 4 sums alongside the
+      // store loop, or re-forming the values from bias / row_add in the second pass, spilled the 128x160 kernels).
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int64_t m = m0 + wm * WM + 16 * i + fr;
@@ -609,6 +631,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
         }
         const bool row_ok = m < p.M;
+        if constexpr (STATS_OK) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = v[j];  // (a register rename) the statistics pass reads the final values
+        }
         const int64_t ms = (dbg & 256) ? (m & 127) : m;  // ablation bit 256: stores land in an L2-resident region
         const bool pitch16_ok = (p.ldo16 & 7) == 0;  // 16-byte f16 stores need an 8-element row pitch
 #pragma unroll
@@ -631,6 +657,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
             } else {
               half4_t h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
               *(half4_t*)(p.out_f16 + ms * p.ldo16 + f) = h;
+            }
+          }
+        }
+      }
+      if constexpr (STATS_OK) {
+        if (p.ch_stats != nullptr) {
+          const int64_t mw = m0 + wm * WM;  // first row of the wave's 64-row block
+          float* const sp = p.ch_stats + (mw >> 6) * 2 * p.N;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, qsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              const f32x4 vm = mw + 16 * i + fr < p.M ? acc[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};  // rows past M contribute nothing
+              ssum += vm;
+              qsum += vm * acc[i][j];
+            }
+            // over the 16 token rows held by the 16 lanes of a DPP row (lanes 16 fg .. 16 fg + 15): rotate-and-add
+            // all-reduce in a fixed association; lane fr == 0 of each row stores its 4 channels
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              ssum[r] = row16_sum(ssum[r]);
+              qsum[r] = row16_sum(qsum[r]);
+            }
+            const int64_t f = n0 + wn * WN + feat_of(j, fg);
+            if (fr == 0 && mw < p.M && f < p.N) {
+              *(f32x4*)(sp + f) = ssum;
+              *(f32x4*)(sp + p.N + f) = qsum;
             }
           }
         }
@@ -812,6 +866,10 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   a.out_f16 = (half_t*)d->out_f16;
   a.out_f8 = (uint8_t*)d->out_f8;
   a.w_exp = (const uint8_t*)d->w_exp;
+  a.ch_stats = d->ch_stats;
+  SEVA_REQUIRE(!d->ch_stats || (d->out_f32 && d->epilogue == 0 && d->N >= 128 && (uintptr_t)d->ch_stats % 16 == 0 &&
+                                d->col_scale_n == 0),
+               "gemm: ch_stats needs the plain epilogue with an fp32 output, N >= 128, no col_scale, a 16-byte aligned buffer");
   a.M = d->M; a.N = d->N; a.K = d->K / KU;
   a.lda = d->lda / KU; a.ldr = d->ldr; a.ldo32 = d->ldo32; a.ldo16 = d->ldo16; a.ldo8 = d->ldo8;
   a.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
@@ -860,6 +918,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     // e4m3 operands: the K >= 640 GEMMs / cin >= 640 convs of the ds2..ds8 levels.  Same tile-shape heuristics.
     bool half_m8 = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
     if (g_seva_knobs.gemm_bm > 0) half_m8 = g_seva_knobs.gemm_bm == 64;
+    if (d->ch_stats) half_m8 = false;  // statistics are emitted per wave-owned 64-row block: 128-row tiles only
     bool wide8 = d->N % 160 == 0;
     if (g_seva_knobs.gemm_bn > 0) wide8 = g_seva_knobs.gemm_bn == 160;
     if (d->epilogue == 1) return half_m8 ? launch<64, 128, 0, 1, true>(a, s) : launch<128, 128, 0, 1, true>(a, s);
@@ -883,6 +942,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   // workgroups, both slots of a CU busy.  SEVA_GEMM_BM=64|128 forces the height (benchmark knob).
   bool half_m = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
   if (g_seva_knobs.gemm_bm > 0) half_m = g_seva_knobs.gemm_bm == 64;
+  if (d->ch_stats) half_m = false;  // statistics are emitted per wave-owned 64-row block: 128-row tiles only
   if (d->epilogue == 1) return half_m ? launch<64, 128, 0, 1>(a, s) : launch<128, 128, 0, 1>(a, s);
   // 128x160 tiles: every channel count of the network (320 .. 10240) is a multiple of 160, so no MFMA
   // column is idle (N = 320: 2 tiles instead of 3 with the last half empty), and a tile needs 10 %

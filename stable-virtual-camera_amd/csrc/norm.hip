@@ -31,6 +31,8 @@ struct GnArgs {
   int64_t ld8;
   half_t* raw_out;  // optional: plain f16 copy of the (concatenated) input, same layout as out
   float* ws;
+  const float* stats1;  // optional: per-channel 64-row-block partial statistics of x1 / x2 from the producing GEMM epilogue
+  const float* stats2;
   int32_t n, hw, c1, c2, groups, dense_c, silu;
   int32_t nslab_stats;  // slabs used by the statistics pass
   int32_t qpb;          // apply pass, channel-split mode: quads per block (gridDim.z > 1)
@@ -116,6 +118,48 @@ __global__ void gn_finalize_kernel(GnArgs p) {
     ss += __shfl_xor(ss, off, 64);
   }
   if (l != 0) return;
+  const double cnt = (double)cpg * (double)p.hw;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float* f = p.ws + p.final_off + ((int64_t)n * p.groups + g) * 2;
+  f[0] = (float)mean;
+  f[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+}
+
+// Same table from the per-channel partial statistics a producing GEMM / conv epilogue wrote (seva_gemm_desc.ch_stats:
+// [n * hw / 64][2][c] per source): no pass over the fp32 tensors.  One 256-thread block per (sample, group); thread t takes
+// the (row block, channel) items t, t + 256, ... in order (channel fastest), fp64; fixed xor tree per wave, then the four
+// wave sums in order: deterministic, and a function of the sample's own blocks only.
+__global__ __launch_bounds__(256) void gn_finalize_ch_kernel(GnArgs p) {
+  __shared__ double red[4][2];
+  const int n = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
+  const int C = p.c1 + p.c2, cpg = C / p.groups;
+  const int nb = p.hw >> 6;
+  const int64_t rb0 = (int64_t)n * nb;
+  const int total = cpg * nb;
+  double s = 0.0, ss = 0.0;
+  for (int idx = t; idx < total; idx += 256) {
+    const int b = idx / cpg, c = g * cpg + (idx - b * cpg);
+    const bool first = c < p.c1;
+    const int cs = first ? p.c1 : p.c2, cl = first ? c : c - p.c1;
+    const float* o = (first ? p.stats1 : p.stats2) + (rb0 + b) * 2 * cs + cl;
+    s += (double)o[0];
+    ss += (double)o[cs];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    ss += __shfl_xor(ss, off, 64);
+  }
+  if ((t & 63) == 0) {
+    red[t >> 6][0] = s;
+    red[t >> 6][1] = ss;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  s = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+  ss = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
   const double cnt = (double)cpg * (double)p.hw;
   const double mean = s / cnt;
   double var = ss / cnt - mean * mean;
@@ -391,6 +435,12 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   SEVA_REQUIRE(a.ld8 >= C && a.ld8 % 4 == 0, "groupnorm: ld_out_f8=%lld invalid", (long long)a.ld8);
   a.n = d->n; a.hw = d->hw; a.c1 = d->c1; a.c2 = d->c2; a.groups = d->groups;
   a.dense_c = d->dense_c; a.silu = d->silu; a.eps = d->eps;
+  a.stats1 = d->stats1; a.stats2 = d->stats2;
+  SEVA_REQUIRE(!d->stats2 || d->stats1, "groupnorm: stats2 without stats1");
+  if (d->stats1) {
+    SEVA_REQUIRE(d->hw % 64 == 0, "groupnorm: producer statistics need hw %% 64 == 0 (hw=%d)", d->hw);
+    SEVA_REQUIRE(d->c2 == 0 || d->stats2, "groupnorm: statistics must be given for BOTH sources (or none)");
+  }
   const int cq = C / 4;
   // wide channel counts get a block of ~cq threads (one quad each) instead of an idle-heavy 256
   const int nthreads = cq <= GN_THREADS ? GN_THREADS : (cq >= GN_MAX_THREADS ? GN_MAX_THREADS : 64 * ((cq + 63) / 64));
@@ -419,15 +469,23 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   if (g_seva_knobs.gn_min_iter > 0) min_iter = g_seva_knobs.gn_min_iter;
   const int nslab_apply = clampi(8192 / (d->n * zchunks), 1, clampi(d->hw / (min_iter * plc_apply), 1, 1024));
   hipStream_t s = (hipStream_t)stream;
-  const double bytes = (double)d->n * d->hw * C * (4.0 + 4.0 + 2.0);
+  const double bytes = (double)d->n * d->hw * C * ((d->stats1 ? 0.0 : 4.0) + 4.0 + 2.0);
   SevaProfScope prof(3, bytes, s);
   const size_t lds = (size_t)plc * C * 2 * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(nthreads), lds, s, a);
-  int rc = seva_check_launch("gn_stats_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->n, d->groups), dim3(64), 0, s, a);
-  rc = seva_check_launch("gn_finalize_kernel");
-  if (rc) return rc;
+  int rc;
+  if (a.stats1) {
+    // statistics came with the data (producer epilogues): only the combine runs
+    hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3(d->n, d->groups), dim3(256), 0, s, a);
+    rc = seva_check_launch("gn_finalize_ch_kernel");
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nslab_stats, d->n), dim3(nthreads), lds, s, a);
+    rc = seva_check_launch("gn_stats_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->n, d->groups), dim3(64), 0, s, a);
+    rc = seva_check_launch("gn_finalize_kernel");
+    if (rc) return rc;
+  }
   if (d->dense)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
   else

@@ -110,6 +110,10 @@ class SevaEngine:
         # for the two-kernel fp8 path, the step stays at 86.1 ms and the error doubles (rel-L2 2.9e-2 -> 5.2e-2).
         self.fp8_pad = _os.environ.get("SEVA_FP8_PAD", "0") == "1"
         self.ff_fused = _os.environ.get("SEVA_FF_FUSED", "1") != "0"  # 0: two-kernel GEGLU + FF2 everywhere (A/B runs)
+        # GroupNorm statistics from the producers' epilogues: 0 off (separate statistics pass everywhere, A/B runs),
+        # 1 where it pays (default), 2 wherever hw % 64 == 0, even on launches that would otherwise run 64-row tiles (tests)
+        self.gn_fused_stats = int(_os.environ.get("SEVA_GN_FUSED_STATS", "1"))
+        self._stats: dict = {}
         self.p = model.params
         self.layout: Layout = model._layout
         self.arena = _Arena(self.device)
@@ -261,6 +265,33 @@ class SevaEngine:
             t.zero_()
         return t
 
+    # GroupNorm statistics emitted by the producing kernel's epilogue (seva_gemm_desc.ch_stats): a tensor that a GroupNorm will
+    # read gets a [rows / 64][2][c] side buffer filled by the conv / GEMM that writes it, and that GroupNorm then skips its
+    # statistics pass over the fp32 tensor.  Only where a 64-row block cannot straddle two samples (hw % 64 == 0: results stay
+    # bitwise independent of the batch composition) and where the launch keeps 128-row tiles anyway.
+    def _stats_buf(self, name, rows, hw, c):
+        if not self.gn_fused_stats or hw % ops.STATS_ROWS or c < 128 or c % 4:
+            return None
+        # small images keep the statistics pass: their launches run 64-row tiles, which have no statistics variant.  The rule
+        # looks at ONE sample (never at the batch size): a sample's result must not depend on what it is batched with
+        if self.gn_fused_stats < 2 and (hw // 128) * ((c + 159) // 160) < 16:
+            return None
+        return self._buf("st:" + name, ops.channel_stats_shape(rows, c), F32)
+
+    def _produced(self, out, st):
+        """Record (or forget) the statistics buffer that travels with fp32 tensor `out`."""
+        if st is None:
+            self._stats.pop(out.data_ptr(), None)
+        else:
+            self._stats[out.data_ptr()] = st
+
+    def _gn_stats(self, x1, x2):
+        s1 = self._stats.get(x1.data_ptr())
+        s2 = None if x2 is None else self._stats.get(x2.data_ptr())
+        if s1 is None or (x2 is not None and s2 is None):
+            return None, None
+        return s1, s2
+
     def _ln(self, x, pfx, rows, c, fp8=False):
         if fp8:
             # e4m3 output, K padded to a multiple of 128: the pad columns are zeroed once (nothing ever writes them again)
@@ -327,21 +358,23 @@ class SevaEngine:
         a8 = self._buf("gn8", (n, hw, cin8), U8, zero=True) if f8_1 else None
         # the 1x1 skip conv (cin != cout) consumes the raw input as f16: emitted by the same GroupNorm pass
         xs16 = self._buf("skip16", (n * hw, cin), F16) if cin != cout else None
+        s1, s2 = self._gn_stats(x1, x2)
         ops.groupnorm(x1, x2, W[pfx + ".in_layers.0.g"], W[pfx + ".in_layers.0.b"], a16, self.gn_ws,
                       eps=1e-5, silu=True, dense=dense, dense_w=W[pfx + ".dense.w"], dense_b=W[pfx + ".dense.b"],
-                      raw_f16=xs16, out_f8=a8)
+                      raw_f16=xs16, out_f8=a8, stats1=s1, stats2=s2)
         hmid = self._buf("res_mid", (n, hw, cout), F32)
+        st_mid = self._stats_buf("res_mid", n * hw, hw, cout)
         off = self.emb_off[pfx]
         if f8_1:
             ops.conv3x3(a8.view(n, h, w, cin8), W[pfx + ".conv1.w8"], w_exp=W[pfx + ".conv1.w8e"], bias=W[pfx + ".conv1.b"],
-                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
+                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid, ch_stats=st_mid)
         else:
             ops.conv3x3(a16.view(n, h, w, cin), W[pfx + ".conv1.w"], bias=W[pfx + ".conv1.b"],
-                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid)
+                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid, ch_stats=st_mid)
         b16 = None if f8_2 else self._buf("gn16", (n, hw, cout), F16)
         b8 = self._buf("gn8", (n, hw, cout8), U8, zero=True) if f8_2 else None
         ops.groupnorm(hmid, None, W[pfx + ".out_layers.0.g"], W[pfx + ".out_layers.0.b"], b16, self.gn_ws,
-                      eps=1e-5, silu=True, out_f8=b8)
+                      eps=1e-5, silu=True, out_f8=b8, stats1=st_mid)
         if cin != cout:
             res = self._buf("skip32", (n * hw, cout), F32)
             ops.gemm(xs16, W[pfx + ".skip.w"], bias=W[pfx + ".skip.b"], out_f32=res)
@@ -349,12 +382,14 @@ class SevaEngine:
             assert x2 is None
             res = x1
         out = self._buf("out:" + pfx, (n, hw, cout), F32)
+        st_out = self._stats_buf("out:" + pfx, n * hw, hw, cout)
         if f8_2:
             ops.conv3x3(b8.view(n, h, w, cout8), W[pfx + ".conv2.w8"], w_exp=W[pfx + ".conv2.w8e"], bias=W[pfx + ".conv2.b"],
-                        residual=res, out_f32=out)
+                        residual=res, out_f32=out, ch_stats=st_out)
         else:
             ops.conv3x3(b16.view(n, h, w, cout), W[pfx + ".conv2.w"], bias=W[pfx + ".conv2.b"],
-                        residual=res, out_f32=out)
+                        residual=res, out_f32=out, ch_stats=st_out)
+        self._produced(out, st_out)
         return out
 
     def _self_attention(self, x32, ln_pfx, at_pfx, rows, c, heads, *, regime, n, hw, T, residual,
@@ -427,7 +462,8 @@ class SevaEngine:
         W, pfx, hw, c, heads = self.W, spec.prefix, h * w, spec.channels, spec.heads
         rows = n * hw
         g16 = self._buf("gn16", (n, hw, c), F16)
-        ops.groupnorm(x, None, W[pfx + ".norm.g"], W[pfx + ".norm.b"], g16, self.gn_ws, eps=1e-6, silu=False)
+        ops.groupnorm(x, None, W[pfx + ".norm.g"], W[pfx + ".norm.b"], g16, self.gn_ws, eps=1e-6, silu=False,
+                      stats1=self._gn_stats(x, None)[0])
         cur = self._buf("t_h", (rows, c), F32)
         ops.gemm(g16.view(rows, c), W[pfx + ".proj_in.w"], bias=W[pfx + ".proj_in.b"], out_f32=cur)
         collapse = lc == 1
@@ -483,8 +519,10 @@ class SevaEngine:
             self._ff(m2, m + ".norm3", m + ".ff", rows, c, residual=h2, out_f32=nxt, out_f16=last16, unit=hw)
             cur = nxt
         out = self._buf("out:" + pfx, (n, hw, c), F32)
+        st_out = self._stats_buf("out:" + pfx, rows, hw, c)
         ops.gemm(last16, W[pfx + ".proj_out.w"], bias=W[pfx + ".proj_out.b"], residual=x.view(rows, c),
-                 out_f32=out.view(rows, c))
+                 out_f32=out.view(rows, c), ch_stats=st_out)
+        self._produced(out, st_out)
         return out
 
     def _resample(self, spec, x, n, h, w):
@@ -495,11 +533,15 @@ class SevaEngine:
         if spec.kind == "down":
             oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
             out = self._buf("out:" + spec.prefix, (n, oh * ow, c), F32)
-            ops.conv3x3(x16, self.W[spec.prefix + ".w"], stride=2, bias=self.W[spec.prefix + ".b"], out_f32=out)
+            st_out = self._stats_buf("out:" + spec.prefix, n * oh * ow, oh * ow, c)
+            ops.conv3x3(x16, self.W[spec.prefix + ".w"], stride=2, bias=self.W[spec.prefix + ".b"], out_f32=out, ch_stats=st_out)
         else:
             oh, ow = 2 * h, 2 * w
             out = self._buf("out:" + spec.prefix, (n, oh * ow, c), F32)
-            ops.conv3x3(x16, self.W[spec.prefix + ".w"], upsample=True, bias=self.W[spec.prefix + ".b"], out_f32=out)
+            st_out = self._stats_buf("out:" + spec.prefix, n * oh * ow, oh * ow, c)
+            ops.conv3x3(x16, self.W[spec.prefix + ".w"], upsample=True, bias=self.W[spec.prefix + ".b"], out_f32=out,
+                        ch_stats=st_out)
+        self._produced(out, st_out)
         return out, oh, ow
 
     # ------------------------------------------------------------------ graph replay
@@ -589,6 +631,7 @@ class SevaEngine:
         lc = y.shape[1]
         t = t.to(torch.int64).contiguous()
         self.gn_ws = self._buf("gn_ws", (n * ops.GN_WORKSPACE_SLABS * 32 * 2,), F32)
+        self._stats = {}
 
         # --- prologue: timestep embedding MLP, all ResBlock emb projections, folded cross-attn ---
         mc, ed = p.model_channels, lay.time_embed_dim
@@ -627,7 +670,9 @@ class SevaEngine:
         x16 = self._buf("x16", (n, h, w, cpad), F16)
         ops.nchw_to_nhwc_f16(x, concat, x16)
         cur = self._buf("out:" + stem.prefix, (n, h * w, stem.cout), F32)
-        ops.conv3x3(x16, W[stem.prefix + ".w"], bias=W[stem.prefix + ".b"], out_f32=cur)
+        st_stem = self._stats_buf("out:" + stem.prefix, n * h * w, h * w, stem.cout)
+        ops.conv3x3(x16, W[stem.prefix + ".w"], bias=W[stem.prefix + ".b"], out_f32=cur, ch_stats=st_stem)
+        self._produced(cur, st_stem)
         ch, cw = h, w
         hs = [(cur, ch, cw)]
 
@@ -654,7 +699,8 @@ class SevaEngine:
         # --- head: GroupNorm + SiLU + conv3x3 (model.py:170-174) ---
         cfin = lay.final_channels
         g16 = self._buf("gn16", (n, ch * cw, cfin), F16)
-        ops.groupnorm(cur, None, W["out.0.g"], W["out.0.b"], g16, self.gn_ws, eps=1e-5, silu=True)
+        ops.groupnorm(cur, None, W["out.0.g"], W["out.0.b"], g16, self.gn_ws, eps=1e-5, silu=True,
+                      stats1=self._gn_stats(cur, None)[0])
         o_nhwc = self._buf("head", (n, ch * cw, p.out_channels), F32)
         ops.conv3x3(g16.view(n, ch, cw, cfin), W["out.2.w"], bias=W["out.2.b"], out_f32=o_nhwc)
         if out is None:

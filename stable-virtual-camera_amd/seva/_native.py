@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
 
@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("oh", c_int32), ("ow", c_int32), ("stride", c_int32), ("upsample", c_int32),
         ("col_scale", c_float), ("col_scale_n", c_int32), ("pad_br_only", c_int32),
         ("w_exp", c_void_p), ("out_f8", c_void_p), ("ldo8", c_int64),
+        ("ch_stats", c_void_p),
     ]
 
 
@@ -69,6 +70,7 @@ class GroupNormDesc(C.Structure):
         ("n", c_int32), ("hw", c_int32), ("c1", c_int32), ("c2", c_int32),
         ("groups", c_int32), ("dense_c", c_int32), ("silu", c_int32), ("eps", c_float),
         ("raw_f16", c_void_p), ("out_f8", c_void_p), ("ld_out_f8", c_int64),
+        ("stats1", c_void_p), ("stats2", c_void_p),
     ]
 
 

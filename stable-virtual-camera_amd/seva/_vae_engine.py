@@ -37,6 +37,9 @@ class _VaeEngineBase:
         self.out_channels = weights.out_channels
         self.latent = weights.latent_channels
         self.arena = _Arena(self.device)
+        import os as _os
+        self.gn_fused_stats = int(_os.environ.get("SEVA_GN_FUSED_STATS", "1"))  # seva/_engine.py: same switch
+        self._stats: dict = {}
         sd = {k: v.detach().to(self.device) for k, v in weights.state_dict().items() if k.startswith(self.PREFIXES)}
         W = {}
 
@@ -83,15 +86,31 @@ class _VaeEngineBase:
             t.zero_()
         return t
 
+    # GroupNorm statistics from the producing conv / GEMM epilogue (same scheme as seva/_engine.py:_stats_buf)
+    def _stats_buf(self, name, rows, hw, c):
+        if not self.gn_fused_stats or hw % ops.STATS_ROWS or c < 128 or c % 4:
+            return None
+        if self.gn_fused_stats < 2 and (hw // 128) * ((c + 159) // 160) < 16:  # per sample, never per batch
+            return None
+        return self._buf("st:" + name, ops.channel_stats_shape(rows, c), F32)
+
+    def _produced(self, out, st):
+        if st is None:
+            self._stats.pop(out.data_ptr(), None)
+        else:
+            self._stats[out.data_ptr()] = st
+
     def _resnet(self, p, x, n, h, w, cin, cout):
         """diffusers ResnetBlock2D (no time embedding): GN-SiLU-conv-GN-SiLU-conv + shortcut."""
         W, hw = self.W, h * w
         a16 = self._buf("gn16", (n, hw, cin), F16)
-        ops.groupnorm(x, None, W[p + ".norm1.g"], W[p + ".norm1.b"], a16, self.gn_ws, eps=1e-6, silu=True)
+        ops.groupnorm(x, None, W[p + ".norm1.g"], W[p + ".norm1.b"], a16, self.gn_ws, eps=1e-6, silu=True,
+                      stats1=self._stats.get(x.data_ptr()))
         mid = self._buf("v_mid", (n, hw, cout), F32)
-        ops.conv3x3(a16.view(n, h, w, cin), W[p + ".conv1.w"], bias=W[p + ".conv1.b"], out_f32=mid)
+        st_mid = self._stats_buf("v_mid", n * hw, hw, cout)
+        ops.conv3x3(a16.view(n, h, w, cin), W[p + ".conv1.w"], bias=W[p + ".conv1.b"], out_f32=mid, ch_stats=st_mid)
         b16 = self._buf("gn16", (n, hw, cout), F16)
-        ops.groupnorm(mid, None, W[p + ".norm2.g"], W[p + ".norm2.b"], b16, self.gn_ws, eps=1e-6, silu=True)
+        ops.groupnorm(mid, None, W[p + ".norm2.g"], W[p + ".norm2.b"], b16, self.gn_ws, eps=1e-6, silu=True, stats1=st_mid)
         if cin != cout:
             xs16 = self._buf("v_sk16", (n * hw, cin), F16)
             ops.cast_concat_f16(x, None, xs16)
@@ -100,7 +119,10 @@ class _VaeEngineBase:
         else:
             res = x
         out = self._buf("out:" + p, (n, hw, cout), F32)
-        ops.conv3x3(b16.view(n, h, w, cout), W[p + ".conv2.w"], bias=W[p + ".conv2.b"], residual=res, out_f32=out)
+        st_out = self._stats_buf("out:" + p, n * hw, hw, cout)
+        ops.conv3x3(b16.view(n, h, w, cout), W[p + ".conv2.w"], bias=W[p + ".conv2.b"], residual=res, out_f32=out,
+                    ch_stats=st_out)
+        self._produced(out, st_out)
         return out
 
     def _attention(self, p, x, n, h, w, c):
@@ -110,7 +132,8 @@ class _VaeEngineBase:
             raise ValueError(f"VAE attention needs h*w % 4 == 0 (got {h}x{w}); latents are multiples of 8 per side")
         hw_pad = 64 * ((hw + 63) // 64)
         g16 = self._buf("gn16", (n, hw, c), F16)
-        ops.groupnorm(x, None, W[p + ".group_norm.g"], W[p + ".group_norm.b"], g16, self.gn_ws, eps=1e-6, silu=False)
+        ops.groupnorm(x, None, W[p + ".group_norm.g"], W[p + ".group_norm.b"], g16, self.gn_ws, eps=1e-6, silu=False,
+                      stats1=self._stats.get(x.data_ptr()))
         q = self._buf("v_q", (n * hw, c), F16)
         k = self._buf("v_k", (n * hw, c), F16)
         ops.gemm(g16.view(n * hw, c), W[p + ".to_q.w"], bias=W[p + ".to_q.b"], out_f16=q)
@@ -126,8 +149,10 @@ class _VaeEngineBase:
             ops.softmax_rows(sc, pr, hw, 1.0 / (c**0.5))
             ops.gemm(pr, vT, bias=W[p + ".to_v.b"], out_f16=att[i * hw:(i + 1) * hw])
         out = self._buf("out:" + p, (n, hw, c), F32)
+        st_out = self._stats_buf("out:" + p, n * hw, hw, c)
         ops.gemm(att, W[p + ".to_out.0.w"], bias=W[p + ".to_out.0.b"], residual=x.view(n * hw, c),
-                 out_f32=out.view(n * hw, c))
+                 out_f32=out.view(n * hw, c), ch_stats=st_out)
+        self._produced(out, st_out)
         return out
 
 
@@ -152,6 +177,7 @@ class VaeDecoderEngine(_VaeEngineBase):
         if cz != self.latent:
             raise ValueError(f"expected {self.latent} latent channels, got {cz}")
         self.gn_ws = self._buf("gn_ws", (n * ops.GN_WORKSPACE_SLABS * 32 * 2,), F32)
+        self._stats = {}
         inv = torch.full((n,), 1.0 / scale_factor, dtype=F32, device=self.device)
         z16 = self._buf("v_z16", (n, h * w, CIN_PAD), F16)
         ops.nchw_to_nhwc_f16(z, None, z16, scale=inv)                      # z / 0.18215, channels-last, padded
@@ -159,7 +185,9 @@ class VaeDecoderEngine(_VaeEngineBase):
         ops.gemm(z16.view(n * h * w, CIN_PAD), W["post_quant_conv.w"], bias=W["post_quant_conv.b"], out_f16=pq)
         top = self.block_out[-1]
         x = self._buf("out:conv_in", (n, h * w, top), F32)
-        ops.conv3x3(pq.view(n, h, w, CIN_PAD), W["decoder.conv_in.w"], bias=W["decoder.conv_in.b"], out_f32=x)
+        st = self._stats_buf("out:conv_in", n * h * w, h * w, top)
+        ops.conv3x3(pq.view(n, h, w, CIN_PAD), W["decoder.conv_in.w"], bias=W["decoder.conv_in.b"], out_f32=x, ch_stats=st)
+        self._produced(x, st)
         x = self._resnet("decoder.mid_block.resnets.0", x, n, h, w, top, top)
         x = self._attention("decoder.mid_block.attentions.0", x, n, h, w, top)
         x = self._resnet("decoder.mid_block.resnets.1", x, n, h, w, top, top)
@@ -175,11 +203,13 @@ class VaeDecoderEngine(_VaeEngineBase):
                 ops.cast_concat_f16(x, None, x16)
                 h, w = 2 * h, 2 * w
                 x = self._buf("out:" + p, (n, h * w, cout), F32)
-                ops.conv3x3(x16, W[p + ".w"], upsample=True, bias=W[p + ".b"], out_f32=x)
+                st = self._stats_buf("out:" + p, n * h * w, h * w, cout)
+                ops.conv3x3(x16, W[p + ".w"], upsample=True, bias=W[p + ".b"], out_f32=x, ch_stats=st)
+                self._produced(x, st)
         c = rev[-1]
         g16 = self._buf("gn16", (n, h * w, c), F16)
         ops.groupnorm(x, None, W["decoder.conv_norm_out.g"], W["decoder.conv_norm_out.b"], g16, self.gn_ws,
-                      eps=1e-6, silu=True)
+                      eps=1e-6, silu=True, stats1=self._stats.get(x.data_ptr()))
         o4 = self._buf("v_o4", (n, h * w, 4), F32)
         ops.conv3x3(g16.view(n, h, w, c), W["decoder.conv_out.w"], bias=W["decoder.conv_out.b"], out_f32=o4)
         out = torch.empty((n, self.out_channels, h, w), dtype=F32, device=self.device)
@@ -212,12 +242,15 @@ class VaeEncoderEngine(_VaeEngineBase):
         if h % (1 << nd) or w % (1 << nd):
             raise ValueError(f"VAE encode needs H and W divisible by {1 << nd} (got {h}x{w})")
         self.gn_ws = self._buf("gn_ws", (n * ops.GN_WORKSPACE_SLABS * 32 * 2,), F32)
+        self._stats = {}
         one = torch.ones((n,), dtype=F32, device=self.device)
         x16 = self._buf("v_x16", (n, h * w, CIN_PAD), F16)
         ops.nchw_to_nhwc_f16(x, None, x16, scale=one)  # channels-last, 3 -> 64 zero-padded channels
         c0 = self.block_out[0]
         cur = self._buf("out:enc_in", (n, h * w, c0), F32)
-        ops.conv3x3(x16.view(n, h, w, CIN_PAD), W["encoder.conv_in.w"], bias=W["encoder.conv_in.b"], out_f32=cur)
+        st = self._stats_buf("out:enc_in", n * h * w, h * w, c0)
+        ops.conv3x3(x16.view(n, h, w, CIN_PAD), W["encoder.conv_in.w"], bias=W["encoder.conv_in.b"], out_f32=cur, ch_stats=st)
+        self._produced(cur, st)
         cin = c0
         for i, cout in enumerate(self.block_out):
             for j in range(2):
@@ -229,14 +262,16 @@ class VaeEncoderEngine(_VaeEngineBase):
                 ops.cast_concat_f16(cur, None, d16)
                 h, w = h // 2, w // 2
                 cur = self._buf("out:" + p, (n, h * w, cout), F32)
-                ops.conv3x3(d16, W[p + ".w"], stride=2, pad_br_only=True, bias=W[p + ".b"], out_f32=cur)
+                st = self._stats_buf("out:" + p, n * h * w, h * w, cout)
+                ops.conv3x3(d16, W[p + ".w"], stride=2, pad_br_only=True, bias=W[p + ".b"], out_f32=cur, ch_stats=st)
+                self._produced(cur, st)
         top = self.block_out[-1]
         cur = self._resnet("encoder.mid_block.resnets.0", cur, n, h, w, top, top)
         cur = self._attention("encoder.mid_block.attentions.0", cur, n, h, w, top)
         cur = self._resnet("encoder.mid_block.resnets.1", cur, n, h, w, top, top)
         g16 = self._buf("gn16", (n, h * w, top), F16)
         ops.groupnorm(cur, None, W["encoder.conv_norm_out.g"], W["encoder.conv_norm_out.b"], g16, self.gn_ws,
-                      eps=1e-6, silu=True)
+                      eps=1e-6, silu=True, stats1=self._stats.get(cur.data_ptr()))
         o4 = self._buf("v_m4", (n, h * w, self.latent), F32)
         ops.conv3x3(g16.view(n, h, w, top), W["enc_out.w"], bias=W["enc_out.b"], out_f32=o4)
         out = torch.empty((n, self.latent, h, w), dtype=F32, device=self.device)

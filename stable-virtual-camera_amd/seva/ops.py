@@ -39,8 +39,11 @@ def gemm(
     col_scale_n: int = 0,
     w_exp: torch.Tensor | None = None,
     out_f8: torch.Tensor | None = None,
+    ch_stats: torch.Tensor | None = None,
 ) -> None:
     """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16).
+    ch_stats (`channel_stats_buffer`): receives per-64-row-block, per-channel sum / sum of squares of out_f32 (GroupNorm
+    statistics emitted by the epilogue; `groupnorm(stats1=...)`).
     Output features < col_scale_n are multiplied by col_scale in fp32 (plain epilogue only).
     fp8 mode (seva_gemm_fp8): a, w are uint8 tensors of e4m3 bytes and w_exp [N] uint8 the weights' E8M0 scale bytes;
     out_f8 (GEGLU epilogue only) receives the hidden activations as e4m3."""
@@ -61,6 +64,7 @@ def gemm(
     d.rows_per_group, d.ld_row_add = rows_per_group, ld_row_add
     d.mode, d.epilogue = 0, 1 if geglu else 0
     d.col_scale, d.col_scale_n = col_scale, col_scale_n
+    d.ch_stats = _stats_ptr(ch_stats, M, N, out_f32)
     if fp8:
         assert w_exp.dtype == U8 and w_exp.numel() == N and (out_f8 is None or out_f8.dtype == U8)
         d.w_exp, d.out_f8 = w_exp.data_ptr(), ptr(out_f8)
@@ -69,6 +73,22 @@ def gemm(
     else:
         assert out_f8 is None
         check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(a.device)), "seva_gemm_f16")
+
+
+STATS_ROWS = 64  # rows per block of the epilogue-emitted GroupNorm statistics (include/seva_hip.h: seva_gemm_desc.ch_stats)
+
+
+def channel_stats_shape(rows: int, channels: int) -> tuple[int, int, int]:
+    """Shape of the f32 buffer a GEMM / conv fills through `ch_stats`: [row blocks][sum | sum of squares][channel]."""
+    return ((rows + STATS_ROWS - 1) // STATS_ROWS, 2, channels)
+
+
+def _stats_ptr(ch_stats, M, N, out_f32):
+    if ch_stats is None:
+        return None
+    assert out_f32 is not None and ch_stats.dtype == F32 and ch_stats.is_contiguous()
+    assert ch_stats.numel() >= ((M + STATS_ROWS - 1) // STATS_ROWS) * 2 * N
+    return ch_stats.data_ptr()
 
 
 FF_FUSED_CHANNELS = (64, 128, 256, 320)
@@ -114,6 +134,7 @@ def conv3x3(
     out_f16: torch.Tensor | None = None,
     pad_br_only: bool = False,
     w_exp: torch.Tensor | None = None,
+    ch_stats: torch.Tensor | None = None,
 ) -> None:
     """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16.
     pad_br_only: zero padding at the bottom / right edge only (diffusers Downsample2D, pad (0,1,0,1)).
@@ -139,6 +160,7 @@ def conv3x3(
     d.n, d.ih, d.iw, d.cin, d.oh, d.ow = n, ih, iw, cin, oh, ow
     d.stride, d.upsample = stride, 1 if upsample else 0
     d.pad_br_only = 1 if pad_br_only else 0
+    d.ch_stats = _stats_ptr(ch_stats, n * oh * ow, w.shape[0], out_f32)
     if fp8:
         assert w_exp.dtype == U8 and w_exp.numel() == w.shape[0]
         d.w_exp = w_exp.data_ptr()
@@ -203,10 +225,14 @@ def groupnorm(
     dense_b: torch.Tensor | None = None,
     raw_f16: torch.Tensor | None = None,
     out_f8: torch.Tensor | None = None,
+    stats1: torch.Tensor | None = None,
+    stats2: torch.Tensor | None = None,
 ) -> None:
     """GroupNorm(+SiLU)(+Pluecker modulation) of cat(x1, x2) -> f16; x: [n, hw, c] f32.
     raw_f16: optional second output, cat(x1, x2) merely cast to f16 (same pass).
-    out_f8: optional e4m3 output (uint8 tensor, same layout); out_f16 may then be None."""
+    out_f8: optional e4m3 output (uint8 tensor, same layout); out_f16 may then be None.
+    stats1 / stats2: the `ch_stats` buffers the kernels that produced x1 / x2 filled (both or none; hw % 64 == 0): the
+    statistics pass over the fp32 tensors is skipped."""
     require_cuda(x1, out_f16 if out_f16 is not None else out_f8)
     n, hw, c1 = x1.shape
     c2 = x2.shape[2] if x2 is not None else 0
@@ -222,6 +248,13 @@ def groupnorm(
     d.dense_c = dense.shape[-1] if dense is not None else 0
     d.silu, d.eps = 1 if silu else 0, eps
     d.raw_f16 = ptr(raw_f16)
+    if stats1 is not None:
+        assert hw % STATS_ROWS == 0 and (x2 is None) == (stats2 is None)
+        assert stats1.dtype == F32 and stats1.numel() >= (n * hw // STATS_ROWS) * 2 * c1
+        assert stats2 is None or (stats2.dtype == F32 and stats2.numel() >= (n * hw // STATS_ROWS) * 2 * c2)
+        d.stats1, d.stats2 = stats1.data_ptr(), ptr(stats2)
+    else:
+        assert stats2 is None
     assert raw_f16 is None or (raw_f16.dtype == F16 and raw_f16.is_contiguous() and raw_f16.numel() == n * hw * (c1 + c2))
     assert workspace.numel() >= n * GN_WORKSPACE_SLABS * groups * 2
     check(_lib().seva_groupnorm_f16(C.byref(d), stream_ptr(x1.device)), "seva_groupnorm_f16")

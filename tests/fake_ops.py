@@ -31,7 +31,27 @@ def dequantize_weight_fp8(w8, w_exp):
     return _from_fp8(w8) * torch.exp2(w_exp.float() - 127.0)[:, None]
 
 
-def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu, out_f8=None):
+STATS_ROWS = 64
+
+
+def channel_stats_shape(rows, channels):
+    return ((rows + STATS_ROWS - 1) // STATS_ROWS, 2, channels)
+
+
+def _emit_stats(acc, ch_stats):
+    """seva_gemm_desc.ch_stats: per 64-row block and channel, sum and sum of squares of the fp32 output."""
+    M, N = acc.shape
+    nb = (M + STATS_ROWS - 1) // STATS_ROWS
+    pad = torch.zeros((nb * STATS_ROWS, N), dtype=F32)
+    pad[:M] = acc
+    blk = pad.view(nb, STATS_ROWS, N)
+    st = ch_stats.view(-1)[: nb * 2 * N].view(nb, 2, N)
+    st[:, 0] = blk.sum(1)
+    st[:, 1] = (blk * blk).sum(1)
+
+
+def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu, out_f8=None,
+              ch_stats=None):
     if geglu:
         if bias is not None:
             acc = acc + bias
@@ -53,10 +73,13 @@ def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, ou
         out_f16.view(M, -1)[:, : acc.shape[1]].copy_(acc.half())
     if out_f8 is not None:
         out_f8.view(M, -1)[:, : acc.shape[1]].copy_(to_fp8(acc))
+    if ch_stats is not None:
+        assert out_f32 is not None and not geglu and N >= 128
+        _emit_stats(acc, ch_stats)
 
 
 def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, residual=None,
-         out_f32=None, out_f16=None, geglu=False, col_scale=1.0, col_scale_n=0, w_exp=None, out_f8=None):
+         out_f32=None, out_f16=None, geglu=False, col_scale=1.0, col_scale_n=0, w_exp=None, out_f8=None, ch_stats=None):
     M, N = a.shape[0], w.shape[0]
     if w_exp is not None:  # seva_gemm_fp8
         assert a.dtype == U8 and w.dtype == U8 and a.shape[1] % 128 == 0 and N % 16 == 0
@@ -70,7 +93,7 @@ def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, resid
             acc = acc + bias
             bias = None
         acc[:, :col_scale_n] *= col_scale
-    _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu, out_f8)
+    _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32, out_f16, geglu, out_f8, ch_stats)
 
 
 FF_FUSED_CHANNELS = (64, 128, 256, 320)
@@ -95,7 +118,7 @@ def ff_fused(a, w1, b1, w2, b2, *, residual=None, out_f32=None, out_f16=None, ln
 
 
 def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
-            ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None):
+            ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None, ch_stats=None):
     n, ih, iw, cin = x.shape
     if w_exp is not None:  # seva_gemm_fp8, conv mode
         assert x.dtype == U8 and w.dtype == U8 and cin % 128 == 0 and w.shape[1] == 9 * cin and not upsample
@@ -113,7 +136,7 @@ def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per
     N = w.shape[0]
     acc = y.permute(0, 2, 3, 1).reshape(-1, N)
     _epilogue(acc, acc.shape[0], N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32,
-              out_f16, False)
+              out_f16, False, ch_stats=ch_stats)
 
 
 def attention(q, k, v, out, *, nb0, nb1, heads, lq, lk, q_strides, k_strides, o_strides, scale=0.125,
@@ -136,12 +159,30 @@ def groupnorm_workspace(n, device):
 
 
 def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, silu=False,
-              dense=None, dense_w=None, dense_b=None, raw_f16=None, out_f8=None):
+              dense=None, dense_w=None, dense_b=None, raw_f16=None, out_f8=None, stats1=None, stats2=None):
     x = torch.cat([x1, x2], -1) if x2 is not None else x1
     if raw_f16 is not None:
         raw_f16.view(x.shape).copy_(x.half())
     C = x.shape[-1]
-    y = F.group_norm(x.transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2)
+    if stats1 is not None:
+        # statistics come from the producers' epilogues (seva_groupnorm_desc.stats1 / stats2): USE them, so that a wrong or
+        # stale buffer handed over by the engine shows up as a wrong result
+        n, hw = x.shape[0], x.shape[1]
+        assert hw % STATS_ROWS == 0 and (x2 is None) == (stats2 is None)
+        nb = hw // STATS_ROWS
+        parts = [stats1.view(-1)[: n * nb * 2 * x1.shape[-1]].view(n, nb, 2, x1.shape[-1])]
+        if x2 is not None:
+            parts.append(stats2.view(-1)[: n * nb * 2 * x2.shape[-1]].view(n, nb, 2, x2.shape[-1]))
+        st = torch.cat(parts, -1).double().sum(1)  # [n, 2, C]
+        cnt = hw * (C // groups)
+        mean = st[:, 0].view(n, groups, -1).sum(-1) / cnt
+        var = (st[:, 1].view(n, groups, -1).sum(-1) / cnt - mean * mean).clamp_min(0.0)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        mean_c = mean.float().repeat_interleave(C // groups, 1)[:, None, :]
+        rstd_c = rstd.float().repeat_interleave(C // groups, 1)[:, None, :]
+        y = (x - mean_c) * rstd_c * gamma + beta
+    else:
+        y = F.group_norm(x.transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2)
     if silu:
         y = F.silu(y)
     if dense is not None:

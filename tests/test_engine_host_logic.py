@@ -121,6 +121,40 @@ def test_engine_orchestration_odd_shapes(patched, T, h, w, lc):
     assert rel_l2(out, O.seva_forward(sd, x, t, y, dense, T)) < 2e-3
 
 
+def test_engine_groupnorm_statistics_from_producer_epilogues(patched, monkeypatch):
+    """GroupNorm statistics emitted by the producing conv / GEMM epilogue (seva_gemm_desc.ch_stats) and consumed through
+    seva_groupnorm_desc.stats1 / stats2: same network output as the separate statistics pass, including the decoder's
+    two-source (skip concat) GroupNorms; the emulated groupnorm USES the buffers it is handed, so a stale or mismatched
+    buffer would show as an O(1) error."""
+    eng, _ = _cpu_engine()
+    g = torch.Generator().manual_seed(29)
+    T, h, w = 2, 32, 32
+    n = 2 * T
+    x, t = torch.randn(n, 11, h, w, generator=g), torch.randint(0, 1000, (n,), generator=g)
+    y, dense = torch.randn(n, 1, 1024, generator=g), torch.randn(n, 6, h, w, generator=g)
+    eng.gn_fused_stats = 0
+    ref = eng.forward(x, None, t, y, dense, T).clone()
+    calls = {"with": 0, "two_source": 0, "without": 0}
+    real = fake_ops.groupnorm
+
+    def counting(x1, x2, *a, **k):
+        if k.get("stats1") is not None:
+            calls["with"] += 1
+            calls["two_source"] += k.get("stats2") is not None
+        else:
+            calls["without"] += 1
+        return real(x1, x2, *a, **k)
+
+    monkeypatch.setattr(fake_ops, "groupnorm", counting)
+    eng.gn_fused_stats = 2  # wherever hw % 64 == 0 and c >= 128 (the default, 1, also asks for >= 320 tiles per launch)
+    out = eng.forward(x, None, t, y, dense, T)
+    err = rel_l2(out, ref)
+    print(f"producer-epilogue statistics vs statistics pass: {err:.2e}; GroupNorms with / without: {calls}")
+    assert calls["with"] >= 8 and calls["two_source"] >= 2 and calls["without"] >= 1
+    # last-bit differences of the statistics re-roll f16 roundings downstream (as in the sliced-chain test below)
+    assert err < 2e-3
+
+
 @pytest.mark.parametrize("frames", [1, 2])
 def test_engine_frame_sliced_chains_match_unsliced(patched, frames):
     """Frame-sliced execution of the LN -> GEMM -> ... chains (engine._slice_rows) is the same computation.  (Bitwise on

@@ -419,6 +419,111 @@ def test_groupnorm(dev, n, hw, c1, c2, silu, dense):
     assert (out.float() - ref).abs().max() < 2e-3 * ref.abs().max()
 
 
+def _block_stats(o32, M, N):
+    """fp64 reference of seva_gemm_desc.ch_stats: [ceil(M / 64)][2][N] sums / sums of squares of the fp32 output."""
+    nb = (M + 63) // 64
+    pad = torch.zeros((nb * 64, N), dtype=torch.float64, device=o32.device)
+    pad[:M] = o32.double()
+    blk = pad.view(nb, 64, N)
+    return torch.stack((blk.sum(1), (blk * blk).sum(1)), 1)
+
+
+@pytest.mark.parametrize("M,N,K,bn", [(640, 320, 320, "0"), (200, 320, 64, "0"), (1000, 640, 128, "0"), (333, 256, 64, "0"),
+                                      (640, 320, 320, "128")])
+def test_gemm_channel_stats(dev, M, N, K, bn, knobs):
+    """Epilogue-emitted GroupNorm statistics of a GEMM output (bias + row_add + residual): exact on integer data,
+    M tails (rows past M contribute nothing), 128- and 160-wide tiles; the output itself is unchanged by the option."""
+    from seva import ops
+    if bn != "0":
+        knobs(gemm_bn=int(bn))
+    a, w = _ints((M, K), -3, 3, dev, 1), _ints((N, K), -2, 2, dev, 2)
+    bias, res = _ints((N,), -3, 3, dev, 3), _ints((M, N), -5, 5, dev, 4)
+    rpg = 48
+    radd = _ints(((M + rpg - 1) // rpg, N), -2, 2, dev, 5)
+    o_ref = torch.empty((M, N), device=dev)
+    ops.gemm(a.half(), w.half(), bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o_ref)
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    st = torch.full(ops.channel_stats_shape(M, N), float("nan"), device=dev)
+    ops.gemm(a.half(), w.half(), bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o32, ch_stats=st)
+    assert torch.equal(o32, o_ref)
+    ref = _block_stats(o32, M, N)
+    assert torch.equal(st.double(), ref), f"max diff {(st.double() - ref).abs().max()}"  # integers: exact in fp32
+    # random data: fp32 sums of 64 values against fp64
+    a, w = _rand((M, K), dev, 6), _rand((N, K), dev, 7, 0.2)
+    ops.gemm(a.half(), w.half(), bias=bias, out_f32=o32, ch_stats=st)
+    ref = _block_stats(o32, M, N)
+    assert (st.double() - ref).abs().max() < 1e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("n,ih,iw,cin,cout,stride,up", [(3, 16, 16, 64, 320, 1, False), (2, 16, 32, 128, 256, 2, False),
+                                                         (2, 8, 8, 64, 128, 1, True), (5, 8, 8, 64, 160, 1, False)])
+def test_conv_channel_stats(dev, n, ih, iw, cin, cout, stride, up):
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    x = _ints((n, ih, iw, cin), -2, 2, dev, 1).half()
+    wc = _ints((cout, cin, 3, 3), -1, 1, dev, 2)
+    bias = _ints((cout,), -3, 3, dev, 3)
+    eh, ew = (2 * ih, 2 * iw) if up else (ih, iw)
+    oh, ow = (eh - 1) // stride + 1, (ew - 1) // stride + 1
+    M = n * oh * ow
+    emb = _ints((n, cout), -2, 2, dev, 4)
+    o32 = torch.full((M, cout), float("nan"), device=dev)
+    st = torch.full(ops.channel_stats_shape(M, cout), float("nan"), device=dev)
+    ops.conv3x3(x, pack_conv3x3(wc).half().to(dev), stride=stride, upsample=up, bias=bias, row_add=emb, rows_per_group=oh * ow,
+                out_f32=o32, ch_stats=st)
+    xi = x.float().permute(0, 3, 1, 2)
+    if up:
+        xi = F.interpolate(xi, scale_factor=2, mode="nearest")
+    ref_o = F.conv2d(xi, wc, bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(M, cout) + emb.repeat_interleave(oh * ow, 0)
+    assert torch.equal(o32, ref_o)
+    assert torch.equal(st.double(), _block_stats(o32, M, cout))
+
+
+@pytest.mark.parametrize("n,hw,c1,c2,dense", [(3, 256, 320, 0, True), (2, 1024, 128, 0, False), (2, 64, 640, 320, True),
+                                              (5, 5184, 320, 320, False)])
+def test_groupnorm_with_producer_statistics(dev, n, hw, c1, c2, dense):
+    """GroupNorm fed with the statistics its producers emitted (stats1 / stats2) against the separate statistics pass and
+    against torch; batch composition does not change a sample's result (bitwise)."""
+    from seva import ops
+    C = c1 + c2
+
+    def produce(c, seed, nn=n, first=0):
+        # the producer: a GEMM with K = 64 whose fp32 output is the GroupNorm input
+        a = _rand((n * hw, 64), dev, seed)[first * hw:(first + nn) * hw].contiguous()
+        w = _rand((c, 64), dev, seed + 1, 0.3)
+        o = torch.empty((nn * hw, c), device=dev)
+        st = torch.empty(ops.channel_stats_shape(nn * hw, c), device=dev)
+        ops.gemm(a.half(), w.half(), bias=_rand((c,), dev, seed + 2), out_f32=o, ch_stats=st)
+        return o.view(nn, hw, c), st
+
+    x1, s1 = produce(c1, 10)
+    x2, s2 = produce(c2, 20) if c2 else (None, None)
+    gamma, beta = 1 + 0.1 * _rand((C,), dev, 3), 0.1 * _rand((C,), dev, 4)
+    kw = dict(dense=_rand((n, hw, 6), dev, 5), dense_w=_rand((2 * C, 6), dev, 6, 0.3), dense_b=_rand((2 * C,), dev, 7, 0.1)) if dense else {}
+    ws = ops.groupnorm_workspace(n, dev)
+    o_pass = torch.empty((n, hw, C), device=dev, dtype=torch.float16)
+    o_st = torch.full_like(o_pass, float("nan"))
+    ops.groupnorm(x1, x2, gamma, beta, o_pass, ws, silu=True, **kw)
+    ops.groupnorm(x1, x2, gamma, beta, o_st, ws, silu=True, stats1=s1, stats2=s2, **kw)
+    x = torch.cat([x1, x2], -1) if c2 else x1
+    ref = F.silu(F.group_norm(x.transpose(1, 2), 32, gamma, beta, 1e-5).transpose(1, 2))
+    if dense:
+        d = kw["dense"] @ kw["dense_w"].T + kw["dense_b"]
+        ref = ref * (1 + d[..., :C]) + d[..., C:]
+    e_pass, e_st = rel_l2(o_pass, ref), rel_l2(o_st, ref)
+    print(f"\ngroupnorm n={n} hw={hw} c={c1}+{c2}: statistics pass {e_pass:.2e}, producer statistics {e_st:.2e}, "
+          f"max |diff| between them {float((o_pass.float() - o_st.float()).abs().max()):.2e}")
+    assert e_st < 6e-4 and rel_l2(o_st, o_pass) < 3e-4
+    # batch invariance: the last sample alone, produced and normalised as a batch of one
+    y1, t1 = produce(c1, 10, 1, n - 1)
+    y2, t2 = produce(c2, 20, 1, n - 1) if c2 else (None, None)
+    assert torch.equal(y1[0], x1[n - 1])
+    o_one = torch.empty((1, hw, C), device=dev, dtype=torch.float16)
+    kw1 = dict(kw, dense=kw["dense"][n - 1:]) if dense else {}
+    ops.groupnorm(y1, y2, gamma, beta, o_one, ops.groupnorm_workspace(1, dev), silu=True, stats1=t1, stats2=t2, **kw1)
+    assert torch.equal(o_one[0], o_st[n - 1])
+
+
 @pytest.mark.parametrize("rows,c", [(10, 64), (1001, 320), (333, 640), (50, 1280), (7, 128)])
 def test_layernorm(dev, rows, c):
     from seva import ops
