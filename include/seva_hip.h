@@ -89,6 +89,14 @@ typedef struct seva_gemm_desc {
    * stored (after bias / row_add / residual); rows >= M contribute nothing.  Per channel, so any grouping or channel
    * concatenation can be formed by the consumer.  Plain epilogue with out_f32 and N >= 128 only; forces 128-row tiles. */
   float* ch_stats;
+  /* optional (NULL = off) workspace that lets seva_gemm_f16 run a convolution over small images (<= 128 output pixels per
+   * sample, K >= 1024: the 9x9 level of a 576x576 step) as split-K = 2 on 128-row tiles: two workgroups per tile, the
+   * upper half of K exported raw, added by the partner before the epilogue (fixed association: deterministic, and chosen
+   * from per-sample dimensions only).  Layout: 16384 int flags (zero before first use; every launch leaves them zero), then
+   * one 128 x BN fp32 tile per output tile: splitk_ws_bytes >= 4 * (16384 + tiles * 128 * 160).  One launch at a time may
+   * use a given workspace (launches on ONE stream are fine). */
+  float* splitk_ws;
+  int64_t splitk_ws_bytes;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 /* BASELINE config 5 ("fp8 weights, CDNA4 fp8 MFMA"): the same operator with BOTH operands in OCP e4m3 (a: [M][lda]

@@ -77,7 +77,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false>
+template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int dbg = DBGK ? p.dbg : 0;
   constexpr int WM = ASTAT ? BM / 4 : BM / 2, WN = ASTAT ? BN : BN / 2;  // per-wave tile
@@ -132,7 +132,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   // block -> (M-tile, chunk of N-tiles).  A block walks its N-tiles itself: the A row-panel is
   // fetched from HBM by the first tile and re-read from L2 by the others, instead of 8..80 sibling
   // blocks all stalling on the same HBM miss for every K-tile.
-  const int work = xcd_remap(blockIdx.x, p.tiles_m * p.n_chunks);
+  // Split-K over TWO workgroups per tile (GemmArgs::sk_ws; the ds8 convs: 27 x 8 tiles of 128 rows cannot fill 512 workgroup
+  // slots, and 64-row tiles move 55 % more LDS-DMA bytes per FLOP with half the MFMA work per barrier).  The first half of
+  // the grid takes the UPPER half of K from zero accumulators and exports them raw to the workspace (producers: lowest
+  // block ids, dispatched first, so a consumer never waits for a workgroup that has not been dispatched); the second half
+  // takes the lower half of K (seeded with the residual as usual), adds the partner's partial and runs the epilogue.
+  // Fixed association -> deterministic, and the same for every batch size (the host picks the split from per-sample
+  // dimensions only).
+  // (its own instantiation, SPLITK: the 128x160 kernels have no registers to spare for it)
+  constexpr bool SPLIT_OK = SPLITK;
+  static_assert(!SPLITK || (EPI == 0 && !PAIRED && !ASTAT && !DBGK && MODE != 2 && BM == 128), "split-K: plain f32 epilogue only");
+  const int nk_all = (int)(p.K / BK);
+  int sk_half = -1, kb = 0, ke = nk_all;  // this block's K-tile range [kb, ke)
+  int bid = blockIdx.x;
+  if constexpr (SPLIT_OK) {
+    if (p.sk_ws != nullptr) {
+      const int nb = p.tiles_m * p.n_chunks;
+      sk_half = bid < nb ? 1 : 0;
+      if (!sk_half) bid -= nb;
+      kb = sk_half ? nk_all / 2 : 0;
+      ke = sk_half ? nk_all : nk_all / 2;
+    }
+  }
+  const int work = xcd_remap(bid, p.tiles_m * p.n_chunks);
   const int tm = work / p.n_chunks, chunk = work - tm * p.n_chunks;
   const int tn_begin = (int)((int64_t)chunk * p.tiles_n / p.n_chunks);
   const int tn_end = (int)((int64_t)(chunk + 1) * p.tiles_n / p.n_chunks);
@@ -207,7 +229,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       // K-tiles are staged in order 0, 1, 2, ...: the (tap row, tap column, channel offset) of the tile being
       // staged is a running scalar state (two integer divisions per K-tile otherwise, emulated on the VALU).
       // block-uniform: a K-tile never straddles taps (cin % 64 == 0)
-      if (kt == 0) st_ky = st_kx = st_ci0 = 0;
+      if (kt == kb) {  // first K-tile of this block's range (0 unless split-K)
+        const int tap = kb * BK / p.cin;
+        st_ci0 = kb * BK - tap * p.cin;
+        st_ky = tap / 3;
+        st_kx = tap - 3 * st_ky;
+      }
       const int ky = st_ky, kx = st_kx, ci0 = st_ci0;
       st_ci0 += BK;
       if (st_ci0 == p.cin) {
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     stage_async(0, 0);
     if (nk > 1) stage_async(1, 1);
   } else {
-    stage(0, 0);
+    stage(0, kb);
   }
   bool stores_flying = false;  // ASYNC: the previous tile's S_ST stores may still be in flight
   for (int tn = tn_begin; tn < tn_end; ++tn) {
@@ -356,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     // its 16 loads per lane are in flight together with this tile's stage-0 DMA and cost no extra
     // registers, instead of four load->wait->store round trips in the epilogue.  Addresses are
     // clamped (M and N tails); the stores are guarded.
-    if (EPI == 0 && p.residual && !(dbg & 32)) {
+    if (EPI == 0 && p.residual && !(dbg & 32) && sk_half != 1) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         int64_t m = m0 + wm * WM + 16 * i + fr;
@@ -405,11 +432,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       if (ASYNC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     auto ktile = [&](int kt) {
-      const int cur = kt & 1;
+      const int cur = (kt - kb) & 1;
       if (ASYNC) {
         if (kt >= 1 && kt + 1 < nk) stage_async(cur ^ 1, kt + 1);  // K-tile 1 was issued a tile ago
       } else {
-        if (kt + 1 < nk && !(dbg & 1)) stage(cur ^ 1, kt + 1);
+        if (kt + 1 < ke && !(dbg & 1)) stage(cur ^ 1, kt + 1);
       }
       const char* const ta = lds_a + cur * A_BYTES;
       const char* const tb = lds_b + cur * B_BYTES;
@@ -499,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       for (int kt = 0; kt < KS_A / 2; ++kt)
         if (kt < nk) ktile(kt);
     } else {
-      for (int kt = 0; kt < nk; ++kt) ktile(kt);
+      for (int kt = kb; kt < ke; ++kt) ktile(kt);
     }
     // bias of THIS tile out of the LDS slot before the next tile's stage 0 overwrites it
     constexpr int NB = NJ;  // GEGLU: per 64-row group [v e=0, v e=1, g e=0, g e=1]
@@ -535,7 +562,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         stage_async(0, 0);
         if (nk > 1) stage_async(1, 1);
       } else {
-        stage(0, 0);
+        stage(0, kb);
+      }
+    }
+    if constexpr (SPLIT_OK) {
+      if (sk_half >= 0) {
+        // workspace: [16384 flags (int)] [per tile: MI x NJ x 256 lanes x f32x4, lane-linear]
+        int* const flag = (int*)p.sk_ws + ((int64_t)tm * p.tiles_n + tn);
+        float* const part = p.sk_ws + 16384 + ((int64_t)tm * p.tiles_n + tn) * (BM * BN) + threadIdx.x * 4;
+        if (sk_half == 1) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) *(f32x4*)(part + (i * NJ + j) * 1024) = acc[i][j];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's stores are visible device-wide ...
+          __syncthreads();                                    // ... for every thread of the workgroup ...
+          if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... then the flag
+          continue;  // no epilogue: the partner finishes the tile
+        }
+        if (threadIdx.x == 0) {
+          // bounded wait (a producer is always dispatched before its consumer; the bound only guards against a hang if that
+          // assumption were ever violated: the tile is then wrong and error slot 16383 counts it)
+          int spins = 0;
+          while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1 << 21)) {
+            __builtin_amdgcn_s_sleep(32);
+            ++spins;
+          }
+          if (spins == (1 << 21)) atomicAdd((int*)p.sk_ws + 16383, 1);
+          __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch / graph replay
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] += *(const f32x4*)(part + (i * NJ + j) * 1024);
       }
     }
     // ASYNC bookkeeping: S_ST is exact only for an interior tile (every guarded store executes) with
@@ -732,11 +793,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false, bool FP8 = false>
+template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false, bool FP8 = false, bool SPLITK = false>
 int launch_p(const GemmArgs& a, hipStream_t s) {
   // + bias slots (ASYNC) + weight-scale slots (FP8 ASYNC)
   constexpr int lds = 2 * ((ASTAT ? 0 : BM) + BN) * 128 + (ASTAT ? 8192 : PAIRED ? 4096 : 0) + (FP8 && PAIRED ? 4096 : 0);
-  constexpr bool DBG_BUILD = !ASTAT && !FP8;  // the ablation instantiation only exists for the staged-A f16 kernels
+  constexpr bool DBG_BUILD = !ASTAT && !FP8 && !SPLITK;  // the ablation instantiation only exists for the staged-A f16 kernels
   // the dynamic-LDS attribute is per device: one bit per device ordinal and instantiation (a second GPU in the
   // same process would otherwise launch 72-80 KB kernels without it)
   static std::atomic<uint64_t> attr_devs{0};
@@ -744,7 +805,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (DBG_BUILD)
       (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED, false>,
@@ -785,7 +846,8 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
   args.n_chunks = chunks;
   args.dbg = g_seva_knobs.gemm_dbg > 0 ? g_seva_knobs.gemm_dbg : 0;
   args.stagger = g_seva_knobs.gemm_stagger > 0 ? g_seva_knobs.gemm_stagger : 0;
-  const int64_t nb = (int64_t)args.tiles_m * chunks;
+  int64_t nb = (int64_t)args.tiles_m * chunks;
+  if (SPLITK) nb *= 2;  // split-K: producers (upper half of K) in the first half of the grid, consumers in the second
   if (nb <= 0 || nb > 0x7fffffff) {
     seva_set_error("gemm: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
@@ -796,7 +858,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
       return seva_check_launch("gemm_kernel");
     }
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8>), dim3((unsigned)nb), dim3(256), lds, s, args);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK>), dim3((unsigned)nb), dim3(256), lds, s, args);
   return seva_check_launch("gemm_kernel");
 }
 
@@ -867,6 +929,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   a.out_f8 = (uint8_t*)d->out_f8;
   a.w_exp = (const uint8_t*)d->w_exp;
   a.ch_stats = d->ch_stats;
+  a.sk_ws = nullptr;
   SEVA_REQUIRE(!d->ch_stats || (d->out_f32 && d->epilogue == 0 && d->N >= 128 && (uintptr_t)d->ch_stats % 16 == 0 &&
                                 d->col_scale_n == 0),
                "gemm: ch_stats needs the plain epilogue with an fp32 output, N >= 128, no col_scale, a 16-byte aligned buffer");
@@ -943,6 +1006,18 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   bool half_m = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
   if (g_seva_knobs.gemm_bm > 0) half_m = g_seva_knobs.gemm_bm == 64;
   if (d->ch_stats) half_m = false;  // statistics are emitted per wave-owned 64-row block: 128-row tiles only
+  // Split-K = 2 for convolutions over SMALL IMAGES (<= 128 output pixels per sample: the ds8 level, 9 x 9) with a long
+  // reduction: 128-row tiles, two workgroups per tile, instead of 64-row tiles.  The choice looks at per-sample dimensions
+  // only, so a sample's result does not depend on the batch size.
+  if (d->splitk_ws && d->mode == 1 && !d->upsample && !narrow && (int64_t)d->oh * d->ow <= 128 && d->K / BK >= 16 &&
+      (d->K / BK) % 2 == 0 && g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0) {
+    const int bn = (g_seva_knobs.gemm_bn > 0 ? g_seva_knobs.gemm_bn == 160 : d->N % 160 == 0) ? 160 : 128;
+    const int64_t tiles = ((d->M + 127) / 128) * ((d->N + bn - 1) / bn);
+    SEVA_REQUIRE(tiles < 16383 && d->splitk_ws_bytes >= (int64_t)(16384 + tiles * 128 * bn) * 4 && (uintptr_t)d->splitk_ws % 16 == 0,
+                 "gemm: splitk_ws too small (%lld bytes for %lld tiles) or misaligned", (long long)d->splitk_ws_bytes, (long long)tiles);
+    a.sk_ws = d->splitk_ws;
+    half_m = false;
+  }
   if (d->epilogue == 1) return half_m ? launch<64, 128, 0, 1>(a, s) : launch<128, 128, 0, 1>(a, s);
   // 128x160 tiles: every channel count of the network (320 .. 10240) is a multiple of 160, so no MFMA
   // column is idle (N = 320: 2 tiles instead of 3 with the last half empty), and a tile needs 10 %
@@ -961,6 +1036,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     return wide ? launch<128, 160, 2, 0>(a, s) : launch<128, 128, 2, 0>(a, s);
   }
   if (narrow) return launch<128, 32, 1, 0>(a, s);
+  if (a.sk_ws) return wide ? launch_p<128, 160, 1, 0, false, false, false, true>(a, s) : launch_p<128, 128, 1, 0, false, false, false, true>(a, s);
   if (half_m) return wide ? launch<64, 160, 1, 0>(a, s) : launch<64, 128, 1, 0>(a, s);
   return wide ? launch<128, 160, 1, 0>(a, s) : launch<128, 128, 1, 0>(a, s);
   }  // !FP8

@@ -114,6 +114,7 @@ class SevaEngine:
         # 1 where it pays (default), 2 wherever hw % 64 == 0, even on launches that would otherwise run 64-row tiles (tests)
         self.gn_fused_stats = int(_os.environ.get("SEVA_GN_FUSED_STATS", "1"))
         self._stats: dict = {}
+        self.conv_splitk = _os.environ.get("SEVA_CONV_SPLITK", "1") != "0"  # 0: 64-row tiles at the 9x9 level (A/B runs)
         self.p = model.params
         self.layout: Layout = model._layout
         self.arena = _Arena(self.device)
@@ -278,6 +279,13 @@ class SevaEngine:
             return None
         return self._buf("st:" + name, ops.channel_stats_shape(rows, c), F32)
 
+    def _sk(self, rows, hw, c):
+        """Split-K workspace for the convs of small images (the 9x9 level): seva_gemm_desc.splitk_ws.  None elsewhere."""
+        if not self.conv_splitk or hw > 128:
+            return None
+        shape = (16384 + ((rows + 127) // 128) * ((c + 127) // 128) * 128 * 160,)
+        return self._buf("sk_ws", shape, F32, zero=True)
+
     def _produced(self, out, st):
         """Record (or forget) the statistics buffer that travels with fp32 tensor `out`."""
         if st is None:
@@ -370,7 +378,8 @@ class SevaEngine:
                         row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid, ch_stats=st_mid)
         else:
             ops.conv3x3(a16.view(n, h, w, cin), W[pfx + ".conv1.w"], bias=W[pfx + ".conv1.b"],
-                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid, ch_stats=st_mid)
+                        row_add=emb_all[:, off:], rows_per_group=hw, ld_row_add=self.emb_total, out_f32=hmid, ch_stats=st_mid,
+                        splitk_ws=self._sk(n * hw, hw, cout))
         b16 = None if f8_2 else self._buf("gn16", (n, hw, cout), F16)
         b8 = self._buf("gn8", (n, hw, cout8), U8, zero=True) if f8_2 else None
         ops.groupnorm(hmid, None, W[pfx + ".out_layers.0.g"], W[pfx + ".out_layers.0.b"], b16, self.gn_ws,
@@ -388,7 +397,7 @@ class SevaEngine:
                         residual=res, out_f32=out, ch_stats=st_out)
         else:
             ops.conv3x3(b16.view(n, h, w, cout), W[pfx + ".conv2.w"], bias=W[pfx + ".conv2.b"],
-                        residual=res, out_f32=out, ch_stats=st_out)
+                        residual=res, out_f32=out, ch_stats=st_out, splitk_ws=self._sk(n * hw, hw, cout))
         self._produced(out, st_out)
         return out
 
@@ -534,7 +543,8 @@ class SevaEngine:
             oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
             out = self._buf("out:" + spec.prefix, (n, oh * ow, c), F32)
             st_out = self._stats_buf("out:" + spec.prefix, n * oh * ow, oh * ow, c)
-            ops.conv3x3(x16, self.W[spec.prefix + ".w"], stride=2, bias=self.W[spec.prefix + ".b"], out_f32=out, ch_stats=st_out)
+            ops.conv3x3(x16, self.W[spec.prefix + ".w"], stride=2, bias=self.W[spec.prefix + ".b"], out_f32=out, ch_stats=st_out,
+                        splitk_ws=self._sk(n * oh * ow, oh * ow, c))
         else:
             oh, ow = 2 * h, 2 * w
             out = self._buf("out:" + spec.prefix, (n, oh * ow, c), F32)

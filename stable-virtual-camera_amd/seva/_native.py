@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ("oh", c_int32), ("ow", c_int32), ("stride", c_int32), ("upsample", c_int32),
         ("col_scale", c_float), ("col_scale_n", c_int32), ("pad_br_only", c_int32),
         ("w_exp", c_void_p), ("out_f8", c_void_p), ("ldo8", c_int64),
-        ("ch_stats", c_void_p),
+        ("ch_stats", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
     ]
 
 

@@ -83,6 +83,12 @@ def channel_stats_shape(rows: int, channels: int) -> tuple[int, int, int]:
     return ((rows + STATS_ROWS - 1) // STATS_ROWS, 2, channels)
 
 
+def splitk_workspace(max_rows: int, max_channels: int, device) -> torch.Tensor:
+    """Zeroed workspace for `conv3x3(splitk_ws=...)`: 16384 flags + one fp32 128 x 160 tile per output tile."""
+    tiles = ((max_rows + 127) // 128) * ((max_channels + 127) // 128)
+    return torch.zeros(16384 + tiles * 128 * 160, dtype=F32, device=device)
+
+
 def _stats_ptr(ch_stats, M, N, out_f32):
     if ch_stats is None:
         return None
@@ -135,6 +141,7 @@ def conv3x3(
     pad_br_only: bool = False,
     w_exp: torch.Tensor | None = None,
     ch_stats: torch.Tensor | None = None,
+    splitk_ws: torch.Tensor | None = None,
 ) -> None:
     """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16.
     pad_br_only: zero padding at the bottom / right edge only (diffusers Downsample2D, pad (0,1,0,1)).
@@ -161,6 +168,9 @@ def conv3x3(
     d.stride, d.upsample = stride, 1 if upsample else 0
     d.pad_br_only = 1 if pad_br_only else 0
     d.ch_stats = _stats_ptr(ch_stats, n * oh * ow, w.shape[0], out_f32)
+    if splitk_ws is not None and not fp8:  # `splitk_workspace`: lets small-image convs run as split-K = 2 (seva_hip.h)
+        assert splitk_ws.dtype == F32 and splitk_ws.is_contiguous()
+        d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * 4
     if fp8:
         assert w_exp.dtype == U8 and w_exp.numel() == w.shape[0]
         d.w_exp = w_exp.data_ptr()

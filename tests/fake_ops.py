@@ -34,6 +34,10 @@ def dequantize_weight_fp8(w8, w_exp):
 STATS_ROWS = 64
 
 
+def splitk_workspace(max_rows, max_channels, device):
+    return torch.zeros(16, dtype=F32)
+
+
 def channel_stats_shape(rows, channels):
     return ((rows + STATS_ROWS - 1) // STATS_ROWS, 2, channels)
 
@@ -118,7 +122,8 @@ def ff_fused(a, w1, b1, w2, b2, *, residual=None, out_f32=None, out_f16=None, ln
 
 
 def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
-            ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None, ch_stats=None):
+            ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None, ch_stats=None,
+            splitk_ws=None):
     n, ih, iw, cin = x.shape
     if w_exp is not None:  # seva_gemm_fp8, conv mode
         assert x.dtype == U8 and w.dtype == U8 and cin % 128 == 0 and w.shape[1] == 9 * cin and not upsample

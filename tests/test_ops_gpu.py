@@ -479,6 +479,42 @@ def test_conv_channel_stats(dev, n, ih, iw, cin, cout, stride, up):
     assert torch.equal(st.double(), _block_stats(o32, M, cout))
 
 
+@pytest.mark.parametrize("n,ih,iw,cin,cout,stride", [(42, 9, 9, 1280, 1280, 1), (5, 9, 9, 256, 320, 1), (42, 18, 18, 640, 1280, 2),
+                                                      (3, 8, 16, 128, 128, 1), (1, 4, 4, 2560, 160, 1)])
+def test_conv_splitk_small_images(dev, n, ih, iw, cin, cout, stride):
+    """Split-K = 2 convolution over small images (seva_gemm_desc.splitk_ws): exact on integer data with bias, row_add and
+    residual; on random data equal to the unsplit kernel up to the one changed association; the flags are left zero (the
+    workspace is reusable by the next launch / graph replay) and the error slot stays 0; batch composition does not matter."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
+    M = n * oh * ow
+    ws = ops.splitk_workspace(M, cout, dev)
+    x = _ints((n, ih, iw, cin), -2, 2, dev, 1).half()
+    wc = _ints((cout, cin, 3, 3), -1, 1, dev, 2)
+    bias, emb, res = _ints((cout,), -3, 3, dev, 3), _ints((n, cout), -2, 2, dev, 4), _ints((M, cout), -4, 4, dev, 5)
+    wp = pack_conv3x3(wc).half().to(dev)
+    o = torch.full((M, cout), float("nan"), device=dev)
+    for _ in range(2):  # twice through the same workspace
+        o.fill_(float("nan"))
+        ops.conv3x3(x, wp, stride=stride, bias=bias, row_add=emb, rows_per_group=oh * ow, residual=res, out_f32=o, splitk_ws=ws)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wc, bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+        ref = ref + emb.repeat_interleave(oh * ow, 0) + res
+        assert torch.equal(o, ref), f"max diff {(o - ref).abs().max()}"
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+    xr, wr = _rand((n, ih, iw, cin), dev, 6).half(), (pack_conv3x3(_rand((cout, cin, 3, 3), dev, 7, 0.05).cpu()).half().to(dev))
+    o1, o2 = torch.empty_like(o), torch.empty_like(o)
+    ops.conv3x3(xr, wr, stride=stride, bias=bias, residual=res, out_f32=o1)
+    ops.conv3x3(xr, wr, stride=stride, bias=bias, residual=res, out_f32=o2, splitk_ws=ws)
+    err = rel_l2(o2, o1)
+    print(f"\nsplit-K conv {n}x{ih}x{iw} {cin}->{cout} s{stride}: vs unsplit {err:.2e}")
+    assert err < 2e-6
+    # one sample alone (batch of one) gives bitwise the rows it has inside the batch
+    o3 = torch.empty((oh * ow, cout), device=dev)
+    ops.conv3x3(xr[n - 1:], wr, stride=stride, bias=bias, residual=res[(n - 1) * oh * ow:], out_f32=o3, splitk_ws=ws)
+    assert torch.equal(o3, o2[(n - 1) * oh * ow:])
+
+
 @pytest.mark.parametrize("n,hw,c1,c2,dense", [(3, 256, 320, 0, True), (2, 1024, 128, 0, False), (2, 64, 640, 320, True),
                                               (5, 5184, 320, 320, False)])
 def test_groupnorm_with_producer_statistics(dev, n, hw, c1, c2, dense):
