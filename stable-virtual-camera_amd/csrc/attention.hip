@@ -69,6 +69,16 @@ __device__ __forceinline__ int k_chunk_swz(int row, int chunk) { return chunk ^ 
 // PRE: q already carries scale*log2(e) (folded into the producing GEMM's fp32 epilogue).  The score
 // accumulators then START at -m_run (splat per key block: 16 moves instead of 32 v_fma), so
 // S^T = K Q^T comes out of the MFMA already in exp2's argument form.
+// max over the two half-waves (lanes l and l ^ 32) in every lane.  v_permlane32_swap exchanges the upper half of its first
+// operand with the lower half of its second: (a, b) = (v, v) -> a = {v.lo, v.lo}, b = {v.hi, v.hi}.  Inline asm: the
+// builtin of this toolchain returns element 0 of its result pair for both elements (checked on a probe kernel); the s_nop
+// covers the VALU-write -> permlane-read wait states the compiler would insert for the builtin.
+__device__ __forceinline__ float half_wave_max(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
 template <int NW, int KT, bool USE_TR, bool DBGK, bool PRE>
 __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   constexpr int KB = KT / 32;               // 32-key blocks per tile
@@ -122,6 +132,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
   // max by up to RESCALE_THR (deferred rescale), so probabilities are bounded by 2^RESCALE_THR.
   constexpr float RESCALE_THR = 8.0f;
   float m_run = PRE ? 0.f : -1e30f, l_run = 0.f;
+  // PRE: -m_run held as a 16-register block = the C operand of the first score MFMA of every key block (rebuilt only when
+  // m_run moves, i.e. in the rare rescale branch, instead of 15 v_mov per tile)
+  f32x16 neg_m[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) neg_m[0][r] = neg_m[1][r] = 0.f;
   const float c = p.scale_log2;
 
   const int nt = (p.lk + KT - 1) / KT;
@@ -169,16 +184,17 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 
   const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
 
-  // One K/V tile.  BUF (LDS buffer) and MASKED (tail tile) are compile-time so that every LDS address
-  // is `per-lane offset + immediate` and the tail mask costs nothing on full tiles.
-  auto tile = [&](auto buf_c, auto masked_c, int kt) {
-    constexpr int BUF = decltype(buf_c)::value;
+  // One K/V tile.  MASKED (tail tile) is compile-time so that the tail mask costs nothing on full tiles.  The LDS buffer
+  // index is a RUN-TIME (wave-uniform) value: with the three buffers as three unrolled copies of this body hipcc gave the
+  // loop-carried O accumulators different registers in different copies and moved all 32 of them (16 v_mov_b64 behind two
+  // `s_nop 11` MFMA-result hazards) in every tile, and rebuilt the 16-register splat of -m_run; one body has one assignment.
+  auto tile = [&](int buf, auto masked_c, int kt) {
     constexpr bool MASKED = decltype(masked_c)::value;
-    const char* const lds_k = smem + BUF * BUF_BYTES;
+    const char* const lds_k = smem + buf * BUF_BYTES;
     const char* const lds_v = lds_k + KT * 128;
     // tile kt+2 -> buffer (kt+2)%3, last read in iteration kt-1 (every wave passed that barrier)
     const bool more2 = kt + 2 < nt && !(dbg & 1);
-    if (more2) issue_tile(kt + 2, (BUF + 2) % 3);
+    if (more2) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);  // (buf + 2) % 3
 
     // ---- S^T = K Q^T ----
     f32x16 sc[KB];
@@ -193,9 +209,12 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
               *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
           if (s == 0) {
             f32x16 c0;
-            const float init = PRE ? -m_run : 0.f;  // PRE: splat(-m_run); else the literal 0
+            if (PRE) {
+              c0 = neg_m[kb & 1];
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c0[r] = init;
+              for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+            }
             sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], c0, 0, 0, 0);
           } else {
             sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kb], 0, 0, 0);
@@ -218,11 +237,18 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     // ---- online softmax, log2 domain, deferred rescale ----
     float mx = -1e30f;
     if (!(dbg & 2)) {
+      // one max chain per key block (independent: half the dependent-issue depth), then the other half-wave's maximum of the
+      // same query by v_permlane32_swap (a VALU op; ds_bpermute costs an LDS round trip and an lgkmcnt(0) per tile)
+      float mk[KB];
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
+      for (int kb = 0; kb < KB; ++kb) {
+        mk[kb] = sc[kb][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 1; r < 16; ++r) mk[kb] = fmaxf(mk[kb], sc[kb][r]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) mx = fmaxf(mx, mk[kb]);
+      mx = half_wave_max(mx);
     }
     if (PRE) {
       // scores are already relative to m_run: rescale when a row maximum exceeds the threshold, and
@@ -232,6 +258,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
         const float delta = first ? mx : fmaxf(mx, 0.f);
         const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
         m_run += delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) neg_m[0][r] = neg_m[1][r] = -m_run;
+        asm volatile("" : "+v"(neg_m[0]), "+v"(neg_m[1]));  // two distinct blocks (not one value the compiler may merge)
         l_run *= alpha;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -260,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
     // probabilities and the truncation cancels in O = sum(p v) / sum(p).
     typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
     const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
-    float lsum = 0.f;
+    float lsum4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent dot2 chains
     half8_t pf[KB][2];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
@@ -283,11 +312,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
             e1 = sc[kb][8 * s2 + 2 * j + 1];
           }
           pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
-          if (!(dbg & 2)) lsum = __builtin_amdgcn_fdot2(pk[j], ones2, lsum, false);
+          if (!(dbg & 2)) lsum4[j] = __builtin_amdgcn_fdot2(pk[j], ones2, lsum4[j], false);
         }
         pf[kb][s2] = __builtin_bit_cast(half8_t, pk);
       }
-    l_run += lsum;
+    l_run += (lsum4[0] + lsum4[1]) + (lsum4[2] + lsum4[3]);
 
     // ---- O^T += V^T P^T ----
     __builtin_amdgcn_s_setprio(1);
@@ -340,19 +369,13 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
   __syncthreads();
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  using B2 = std::integral_constant<int, 2>;
-  const int nfull = p.lk / KT;  // tiles that need no mask
-  auto run = [&](auto buf_c, int kt) {
-    if (kt < nfull) tile(buf_c, std::false_type{}, kt);
-    else tile(buf_c, std::true_type{}, kt);
-  };
-  for (int kt = 0; kt < nt; kt += 3) {  // buffer index == tile % 3
-    run(B0{}, kt);
-    if (kt + 1 < nt) run(B1{}, kt + 1);
-    if (kt + 2 < nt) run(B2{}, kt + 2);
+  const int nfull = p.lk / KT;  // tiles that need no mask (the ragged tail tile, if any, is the last one)
+  int buf = 0;                  // buffer index == tile % 3
+  for (int kt = 0; kt < nfull; ++kt) {
+    tile(buf, std::false_type{}, kt);
+    buf = buf == 2 ? 0 : buf + 1;
   }
+  if (nfull < nt) tile(buf, std::true_type{}, nfull);
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
