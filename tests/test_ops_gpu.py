@@ -246,7 +246,7 @@ QK_C = 0.125 * 1.4426950408889634
 @pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 200, 200), (1, 1, 1701, 1701), (2, 3, 70, 5), (4, 2, 21, 21),
                                        (1, 2, 33, 64), (2, 1, 500, 777), (2, 2, 1024, 900), (1, 3, 777, 1300)])
 @pytest.mark.parametrize("spike", [False, True])
-@pytest.mark.parametrize("two", ["0", "1"])
+@pytest.mark.parametrize("two", ["0", "1", "3"])
 def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, knobs):
     """q already multiplied by scale*log2(e) (what the engine's QKV projection emits): the kernel starts
     its score accumulators at -m_run and exponentiates the MFMA output directly.  `spike` plants, late in
