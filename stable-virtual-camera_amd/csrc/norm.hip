@@ -246,7 +246,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
           wmod[r][j] = f32x2{j < dc ? w0 : 0.f, j < dc ? w1 : 0.f};
         }
     }
-    constexpr int U = 2;  // pixels in flight per thread
+    constexpr int U = DENSE ? 3 : 2;  // pixels in flight per thread (modulated: 3 waves per SIMD need 4 to keep ~12 MB in flight)
     for (int pix0 = p_begin + pl; pix0 < p_end; pix0 += U * pl_count) {
       f32x4 v[U];
       float dn[U][GN_MAX_DENSE];
