@@ -410,18 +410,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two-chain variant for long sequences (engine path: pre-scaled q, tr-reads): a wave owns 64 query
-// rows as two independent 32-row chains A and B at 2 waves/SIMD.  Within one tile the order is
-//   QK(A) | QK(B) + softmax(A) | PV(A) + softmax(B) | PV(B)
-// so that one chain's exp/cvt VALU work issues in the shadow of the other chain's MFMAs inside ONE
-// instruction stream (the three-waves-per-SIMD kernel above relies on the hardware interleaving
-// separate waves, which barrier and wait stalls defeat about 40 % of the time).  Same LDS ring,
-// operand layouts, online-softmax arithmetic and rounding as attn_kernel<4, 64, true, false, true>.
-// SCHED (knob attn_two = 2): the same arithmetic, re-ordered so that each chain's exp / pack VALU work sits in ONE basic
-// block with the OTHER chain's MFMAs, and pinned there with sched_group_barrier (1 LDS read + 1 MFMA + 4 transcendental + 6
-// VALU per group).  The wave-uniform rescale branches stay outside those blocks:
-//   [QK(A), max(A)] -rescale A?- [QK(B) || exp(A), max(B)] -rescale B?- [PV(A) || exp(B)] [PV(B)]
-template <int KT, bool SCHED = false>
+// Two-query-block variant for long sequences (engine path: pre-scaled q, tr-reads): a wave owns 64 query rows as two 32-row
+// blocks A and B (2 waves per SIMD) and every K fragment and V^T fragment it reads from LDS feeds BOTH blocks' MFMAs:
+//   scores(A, B) | softmax(A) | softmax(B) | PV(A, B)
+// Per query that is half the LDS fragment reads, half the K/V LDS-DMA bytes and instructions (a workgroup's tile serves 256
+// queries) and half the per-tile bookkeeping of attn_kernel -- the components whose costs ADD UP there (ablations of
+// the pipelined kernel).  Same LDS ring, operand layouts, online-softmax arithmetic and rounding as
+// attn_kernel<4, 64, true, false, true>; one loop body with a run-time buffer index, running source pointers, half-wave maximum
+// by v_permlane32_swap (as there).
+template <int KT>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   constexpr int NW = 4, QB = 2, KB = KT / 32;
   __shared__ __attribute__((aligned(16))) char smem[3 * 2 * KT * 128];
@@ -478,39 +475,59 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   const unsigned smem_base =
       __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
   const int sr = lane >> 3, sp = lane & 7;
-  auto issue_tile = [&](int kt, int buf) {
+  const half_t* kp[IP];
+  const half_t* vp[IP];
+#pragma unroll
+  for (int i = 0; i < IP; ++i) {
+    const int row = 8 * (wave_u * IP + i) + sr;
+    const int key = row < p.lk ? row : p.lk - 1;
+    kp[i] = kbase + (int64_t)key * p.k_sl + k_chunk_swz(row, sp) * 8;
+    vp[i] = vbase + (int64_t)key * p.k_sl + v_chunk_swz(row, sp) * 8;
+  }
+  const int64_t tile_stride = (int64_t)KT * p.k_sl;
+  const bool ragged = (p.lk % KT) != 0;
+  auto issue_tile = [&](int kt, int buf) {  // tiles are issued strictly in order 0, 1, 2, ...
+    const bool clamp = ragged && kt == nt - 1 && kt > 0;
 #pragma unroll
     for (int i = 0; i < IP; ++i) {
-      const int row = 8 * (wave_u * IP + i) + sr;
-      int key = kt * KT + row;
-      if (key >= p.lk) key = p.lk - 1;
-      const int64_t roff = (int64_t)key * p.k_sl;
       const unsigned dst = smem_base + buf * BUF_BYTES + 8 * (wave_u * IP + i) * 128;
-      glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
-      glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
+      if (clamp) {
+        const int row = 8 * (wave_u * IP + i) + sr;
+        int key = kt * KT + row;
+        if (key >= p.lk) key = p.lk - 1;
+        const int64_t roff = (int64_t)key * p.k_sl;
+        glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
+        glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
+      } else {
+        glds16_raw(kp[i], dst);
+        glds16_raw(vp[i], dst + KT * 128);
+      }
+      kp[i] += tile_stride;
+      vp[i] += tile_stride;
     }
   };
   const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
   typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+  const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
 
-  auto tile = [&](auto buf_c, auto masked_c, int kt) {
-    constexpr int BUF = decltype(buf_c)::value;
+  auto tile = [&](int buf, auto masked_c, int kt) {
     constexpr bool MASKED = decltype(masked_c)::value;
-    const char* const lds_k = smem + BUF * BUF_BYTES;
+    const char* const lds_k = smem + buf * BUF_BYTES;
     const char* const lds_v = lds_k + KT * 128;
     const bool more2 = kt + 2 < nt;
-    if (more2) issue_tile(kt + 2, (BUF + 2) % 3);
+    if (more2) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);  // (buf + 2) % 3
 
+    // ---- S^T = K Q^T for both query blocks off ONE K fragment; accumulators start at -m_run (q carries scale*log2e) ----
     f32x16 sc[QB][KB];
-    half8_t pf[QB][KB][2];
-    // S^T = K Q^T, accumulators start at -m_run (q carries scale*log2e)
-    auto qk = [&](int c) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const int krow = 32 * kb + qi;
+    for (int kb = 0; kb < KB; ++kb) {
+      const int krow = 32 * kb + qi;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const half8_t kf = *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
+      for (int s = 0; s < 4; ++s) {
+        const half8_t kf = *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
+#pragma unroll
+        for (int c = 0; c < QB; ++c) {
           if (s == 0) {
             f32x16 c0;
             const float init = -m_run[c];
@@ -522,9 +539,12 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
           }
         }
       }
-    };
-    // softmax split in two: the part that may branch (mask, running max, rare rescale) and the branch-free exp / pack part
-    auto rescale_part = [&](int c) {
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // ---- online softmax per query block: mask, running maximum, rare rescale; exp2 / pack / row sums ----
+    half8_t pf[QB][KB][2];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
       if (MASKED) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -534,14 +554,19 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
             if (key >= p.lk) sc[c][kb][r] = -1e30f;
           }
       }
-      float mx = -1e30f;
+      float mk[KB];
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
+      for (int kb = 0; kb < KB; ++kb) {
+        mk[kb] = sc[c][kb][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[c][kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 1; r < 16; ++r) mk[kb] = fmaxf(mk[kb], sc[c][kb][r]);
+      }
+      float mx = mk[0];
+#pragma unroll
+      for (int kb = 1; kb < KB; ++kb) mx = fmaxf(mx, mk[kb]);
+      mx = half_wave_max(mx);
       const bool first = kt == 0;
-      if (first || __any(mx > RESCALE_THR)) {  // wave-uniform
+      if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {  // wave-uniform, rare
         const float delta = first ? mx : fmaxf(mx, 0.f);
         const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
         m_run[c] += delta;
@@ -555,10 +580,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[c][kb][r] -= delta;
       }
-    };
-    auto exp_part = [&](int c) {
-      const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
-      float ls0 = 0.f, ls1 = 0.f;  // two partial sums: shorter dependent dot2 chains
+      float ls[4] = {0.f, 0.f, 0.f, 0.f};  // four partial sums: short dependent dot2 chains
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -569,78 +591,31 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
             const float e0 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j]);
             const float e1 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j + 1]);
             pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
-            if (j & 1) ls1 = __builtin_amdgcn_fdot2(pk[j], ones2, ls1, false);
-            else ls0 = __builtin_amdgcn_fdot2(pk[j], ones2, ls0, false);
+            ls[j] = __builtin_amdgcn_fdot2(pk[j], ones2, ls[j], false);
           }
           pf[c][kb][s2] = __builtin_bit_cast(half8_t, pk);
         }
-      l_run[c] += ls0 + ls1;
-    };
-    auto softmax = [&](int c) {
-      rescale_part(c);
-      exp_part(c);
-    };
-    auto pv = [&](int c) {
+      l_run[c] += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    }
+    // ---- O^T += V^T P^T for both query blocks off ONE V^T fragment ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int r0 = 32 * kb + 16 * s2 + 4 * hh;
-            const int colbyte = (32 * db + 16 * (g16 & 1) + 4 * p4) * 2;
-            const int ch = colbyte >> 4, within = colbyte & 15;
-            const int ra = r0 + q4, rb = r0 + 8 + q4;
-            const half8_t vf = tr_read_pair(lds_v + ra * 128 + (v_chunk_swz(ra, ch) << 4) + within,
-                                            lds_v + rb * 128 + (v_chunk_swz(rb, ch) << 4) + within);
-            acc_o[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c][kb][s2], acc_o[c][db], 0, 0, 0);
-          }
-    };
-    if constexpr (SCHED) {
-      constexpr int NM = 4 * KB;  // MFMAs of one chain's QK (and of half of its PV)
-      qk(0);
-      rescale_part(0);
-      // ---- block 1: QK(B) MFMAs with exp / pack of chain A in their shadow ----
-      __builtin_amdgcn_sched_barrier(0);
-      qk(1);
-      exp_part(0);
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (the MFMA's K fragment)
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);  // 4 x v_exp_f32
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // cvt_pkrtz / dot2 / accumulator splats
-      }
-      // pin chain A's packed probabilities HERE: they are first used in block 2, and LLVM's IR-level sinking would otherwise
-      // move the whole exp / pack computation down to that use (out of the MFMAs' shadow)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) asm volatile("" : "+v"(pf[0][kb][s2]));
-      asm volatile("" : "+v"(l_run[0]));
-      __builtin_amdgcn_sched_barrier(0);
-      rescale_part(1);
-      // ---- block 2: PV(A) MFMAs with exp / pack of chain B in their shadow, then PV(B) ----
-      __builtin_amdgcn_sched_barrier(0);
-      pv(0);
-      exp_part(1);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int r0 = 32 * kb + 16 * s2 + 4 * hh;
+          const int colbyte = (32 * db + 16 * (g16 & 1) + 4 * p4) * 2;
+          const int ch = colbyte >> 4, within = colbyte & 15;
+          const int ra = r0 + q4, rb = r0 + 8 + q4;
+          const half8_t vf = tr_read_pair(lds_v + ra * 128 + (v_chunk_swz(ra, ch) << 4) + within,
+                                          lds_v + rb * 128 + (v_chunk_swz(rb, ch) << 4) + within);
 #pragma unroll
-      for (int i = 0; i < 2 * NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the tr-read pair of the MFMA's V fragment
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      pv(1);
-    } else {
-      qk(0);
-      qk(1);
-      softmax(0);
-      pv(0);
-      softmax(1);
-      pv(1);
-    }
+          for (int c = 0; c < QB; ++c)
+            acc_o[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c][kb][s2], acc_o[c][db], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
     if (more2) wait_vm<G>();
     else wait_vm<0>();
     __syncthreads();
@@ -658,19 +633,13 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[c][s]));  // retire the Q loads (see attn_kernel)
   __syncthreads();
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  using B2 = std::integral_constant<int, 2>;
   const int nfull = p.lk / KT;
-  auto run = [&](auto buf_c, int kt) {
-    if (kt < nfull) tile(buf_c, std::false_type{}, kt);
-    else tile(buf_c, std::true_type{}, kt);
-  };
-  for (int kt = 0; kt < nt; kt += 3) {
-    run(B0{}, kt);
-    if (kt + 1 < nt) run(B1{}, kt + 1);
-    if (kt + 2 < nt) run(B2{}, kt + 2);
+  int buf = 0;
+  for (int kt = 0; kt < nfull; ++kt) {
+    tile(buf, std::false_type{}, kt);
+    buf = buf == 2 ? 0 : buf + 1;
   }
+  if (nfull < nt) tile(buf, std::true_type{}, nfull);
 
   __syncthreads();  // every wave is done reading K/V tiles
 #pragma unroll
@@ -1098,27 +1067,11 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   const bool pre = d->q_prescaled != 0;
   SEVA_REQUIRE(!pre || use_tr, "attention: q_prescaled is not available on the SEVA_ATTN_NO_TR debug path");
   if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr, pre);
-  // Two-chain kernel: opt-in (SEVA_ATTN_TWO=1).  Measured at the headline shapes it ties with attn_kernel
-  // (27.5 vs 27.3 ms/step): hipcc issues both chains' Q*K groups up front, the wave-uniform rescale
-  // branches split the tile into basic blocks it does not schedule across, and 38 + 32 register moves per
-  // tile appear at 251 VGPRs.  Kept, bit-compatible and tested, as the base for a hand-scheduled version.
-  // Software-pipelined kernel: opt-in (knob attn_two = 3).  Correct (same tests as attn_kernel) and 0.5-2.6 % faster at the
-  // three long-sequence shapes of a step -- not the 1.5x its slot arithmetic promises: see DESIGN.md (ablations: the costs of
-  // the score MFMAs, the PV MFMAs, the exp stream, the K/V LDS-DMA and the fragment reads ADD UP in this kernel too).
-  if (pre && use_tr && !a.dbg && g_seva_knobs.attn_two == 3) {
-    AttnArgs args = a;
-    // (an 8-wave workgroup -- 256 queries per K/V tile, half the LDS-DMA bytes per FLOP, one workgroup per CU -- was measured
-    // too: 834 vs 867 TFLOP/s at ds2 joint)
-    args.qblocks = (a.lq + 127) / 128;
-    const int64_t nb = batch * a.heads * args.qblocks;
-    if (nb <= 0 || nb > 0x7fffffff) {
-      seva_set_error("attention: bad grid %lld", (long long)nb);
-      return SEVA_ERR_ARG;
-    }
-    hipLaunchKernelGGL((attn3_kernel<64, 4>), dim3((unsigned)nb), dim3(256), 0, s, args);
-    return seva_check_launch("attn3_kernel");
-  }
-  if (pre && use_tr && !a.dbg && d->lq >= 512 && (g_seva_knobs.attn_two == 1 || g_seva_knobs.attn_two == 2)) {
+  // Two-query-block kernel (64 queries per wave, K / V fragments shared by both blocks): the default for long sequences
+  // (+3.6 ... +6.2 % at the three long shapes of a step, -1 % at L = 1296).  Knob attn_two: 0 forces attn_kernel, 1 selects this
+  // kernel from lq >= 512, 3 the software-pipelined kernel above.
+  const int two = g_seva_knobs.attn_two;
+  if (pre && use_tr && !a.dbg && ((two < 0 && d->lq >= 2048) || ((two == 1 || two == 2) && d->lq >= 512))) {
     AttnArgs args = a;
     args.qblocks = (a.lq + 255) / 256;
     const int64_t nb = batch * a.heads * args.qblocks;
@@ -1126,8 +1079,7 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
       seva_set_error("attention: bad grid %lld", (long long)nb);
       return SEVA_ERR_ARG;
     }
-    if (g_seva_knobs.attn_two == 2) hipLaunchKernelGGL((attn2_kernel<64, true>), dim3((unsigned)nb), dim3(256), 0, s, args);
-    else hipLaunchKernelGGL((attn2_kernel<64, false>), dim3((unsigned)nb), dim3(256), 0, s, args);
+    hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
     return seva_check_launch("attn2_kernel");
   }
   return launch<4, 64>(a, batch, s, use_tr, pre);
