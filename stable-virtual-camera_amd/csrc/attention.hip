@@ -457,6 +457,9 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
       qf[c][s] = *(const half8_t*)(qbase + (int64_t)qrow_c * p.q_sl + 16 * s + 8 * hh);
   }
 
+  // a wave whose 64 query rows all lie past lq (ragged last query block: 5184 = 20.25 x 256) keeps feeding the K/V ring and
+  // meeting the barriers but computes nothing: its MFMA / VALU / LDS-read slots go to the other workgroup on the CU
+  const bool active = __builtin_amdgcn_readfirstlane(qb * (32 * QB * NW) + wave * (32 * QB)) < p.lq;
   f32x16 acc_o[QB][2];
   float m_run[QB], l_run[QB];
 #pragma unroll
@@ -517,6 +520,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
     const bool more2 = kt + 2 < nt;
     if (more2) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);  // (buf + 2) % 3
 
+    if (active) {
     // ---- S^T = K Q^T for both query blocks off ONE K fragment; accumulators start at -m_run (q carries scale*log2e) ----
     f32x16 sc[QB][KB];
     __builtin_amdgcn_s_setprio(1);
@@ -616,6 +620,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
             acc_o[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c][kb][s2], acc_o[c][db], 0, 0, 0);
         }
     __builtin_amdgcn_s_setprio(0);
+    }  // active
     if (more2) wait_vm<G>();
     else wait_vm<0>();
     __syncthreads();
