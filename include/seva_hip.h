@@ -97,9 +97,6 @@ typedef struct seva_gemm_desc {
    * use a given workspace (launches on ONE stream are fine). */
   float* splitk_ws;
   int64_t splitk_ws_bytes;
-  /* rows per block of ch_stats: 0 / 64 (default) or 16 (four times the buffer, [ceil(M / 16)][2][N]; for images whose pixel count
-   * is a multiple of 16 but not of 64, e.g. 36 x 36) */
-  int32_t ch_stats_rows;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 /* BASELINE config 5 ("fp8 weights, CDNA4 fp8 MFMA"): the same operator with BOTH operands in OCP e4m3 (a: [M][lda]
@@ -204,7 +201,6 @@ typedef struct seva_groupnorm_desc {
    * belongs to one sample and a sample's statistics stay bitwise independent of the batch). */
   const float* stats1;
   const float* stats2;
-  int32_t stats_rows; /* rows per block of stats1 / stats2: 0 / 64 or 16 (hw must be a multiple of it) */
 } seva_groupnorm_desc;
 int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
 

@@ -723,30 +723,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         }
       }
       if constexpr (STATS_OK) {
-        if (p.ch_stats != nullptr && p.stats_rows == 16) {
-          // 16-row granularity (images whose pixel count is a multiple of 16 but not of 64: 36 x 36): one partial per MFMA row block
-          const int64_t mw = m0 + wm * WM;
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            const bool row_in = mw + 16 * i + fr < p.M;
-            float* const sp = p.ch_stats + ((mw >> 4) + i) * 2 * p.N;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-              f32x4 ssum = row_in ? acc[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};
-              f32x4 qsum = ssum * acc[i][j];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                ssum[r] = row16_sum(ssum[r]);
-                qsum[r] = row16_sum(qsum[r]);
-              }
-              const int64_t f = n0 + wn * WN + feat_of(j, fg);
-              if (fr == 0 && mw + 16 * i < p.M && f < p.N) {
-                *(f32x4*)(sp + f) = ssum;
-                *(f32x4*)(sp + p.N + f) = qsum;
-              }
-            }
-          }
-        } else if (p.ch_stats != nullptr) {
+        if (p.ch_stats != nullptr) {
           const int64_t mw = m0 + wm * WM;  // first row of the wave's 64-row block
           float* const sp = p.ch_stats + (mw >> 6) * 2 * p.N;
 #pragma unroll
@@ -952,8 +929,6 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   a.out_f8 = (uint8_t*)d->out_f8;
   a.w_exp = (const uint8_t*)d->w_exp;
   a.ch_stats = d->ch_stats;
-  a.stats_rows = d->ch_stats_rows == 16 ? 16 : 64;
-  SEVA_REQUIRE(d->ch_stats_rows == 0 || d->ch_stats_rows == 16 || d->ch_stats_rows == 64, "gemm: ch_stats_rows must be 0 (= 64), 16 or 64");
   a.sk_ws = nullptr;
   SEVA_REQUIRE(!d->ch_stats || (d->out_f32 && d->epilogue == 0 && d->N >= 128 && (uintptr_t)d->ch_stats % 16 == 0 &&
                                 d->col_scale_n == 0),

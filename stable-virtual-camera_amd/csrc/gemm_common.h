@@ -15,8 +15,7 @@ struct SevaGemmArgs {
   uint8_t* out_f8;        // FP8 kernels, GEGLU epilogue: e4m3 hidden activations (the next fp8 GEMM's A operand)
   const uint8_t* w_exp;   // FP8 kernels: per-output-channel E8M0 scale byte (127 + e): weight row n is q_n * 2^e
   float* sk_ws;           // split-K workspace (flags + raw partial tiles), or null: see gemm.hip
-  float* ch_stats;        // optional [ceil(M / R)][2][N]: per R-row block and output channel, sum and sum of squares of out_f32
-  int32_t stats_rows;     // R: 64 (one block per wave) or 16 (one per 16-row MFMA block: images of hw % 16 == 0 pixels)
+  float* ch_stats;        // optional [ceil(M / 64)][2][N]: per 64-row block and output channel, sum and sum of squares of out_f32
   int64_t M, N, K;        // FP8 kernels: K, lda, cin count 2-byte units (= pairs of e4m3 elements)
   int64_t lda, ldr, ldo32, ldo16, ldo8;
   int64_t rows_per_group, ldra;

@@ -33,7 +33,6 @@ struct GnArgs {
   float* ws;
   const float* stats1;  // optional: per-channel 64-row-block partial statistics of x1 / x2 from the producing GEMM epilogue
   const float* stats2;
-  int32_t stats_rows;   // rows per block of stats1 / stats2: 64 or 16
   int32_t n, hw, c1, c2, groups, dense_c, silu;
   int32_t nslab_stats;  // slabs used by the statistics pass
   int32_t qpb;          // apply pass, channel-split mode: quads per block (gridDim.z > 1)
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(256) void gn_finalize_ch_kernel(GnArgs p) {
   __shared__ double red[4][2];
   const int n = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
   const int C = p.c1 + p.c2, cpg = C / p.groups;
-  const int nb = p.hw / p.stats_rows;
+  const int nb = p.hw >> 6;
   const int64_t rb0 = (int64_t)n * nb;
   const int total = cpg * nb;
   double s = 0.0, ss = 0.0;
@@ -439,9 +438,7 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   a.stats1 = d->stats1; a.stats2 = d->stats2;
   SEVA_REQUIRE(!d->stats2 || d->stats1, "groupnorm: stats2 without stats1");
   if (d->stats1) {
-    a.stats_rows = d->stats_rows == 16 ? 16 : 64;
-    SEVA_REQUIRE(d->stats_rows == 0 || d->stats_rows == 16 || d->stats_rows == 64, "groupnorm: stats_rows must be 0 (= 64), 16 or 64");
-    SEVA_REQUIRE(d->hw % a.stats_rows == 0, "groupnorm: producer statistics need hw %% %d == 0 (hw=%d)", a.stats_rows, d->hw);
+    SEVA_REQUIRE(d->hw % 64 == 0, "groupnorm: producer statistics need hw %% 64 == 0 (hw=%d)", d->hw);
     SEVA_REQUIRE(d->c2 == 0 || d->stats2, "groupnorm: statistics must be given for BOTH sources (or none)");
   }
   const int cq = C / 4;

@@ -111,8 +111,7 @@ class SevaEngine:
         self.fp8_pad = _os.environ.get("SEVA_FP8_PAD", "0") == "1"
         self.ff_fused = _os.environ.get("SEVA_FF_FUSED", "1") != "0"  # 0: two-kernel GEGLU + FF2 everywhere (A/B runs)
         # GroupNorm statistics from the producers' epilogues: 0 off (separate statistics pass everywhere, A/B runs),
-        # 1 where it pays (default: 64-row blocks, images of hw % 64 == 0 pixels), 2 wherever possible: also 16-row blocks
-        # (hw % 16 == 0) and launches that would otherwise run 64-row tiles (tests)
+        # 1 where it pays (default), 2 wherever hw % 64 == 0, even on launches that would otherwise run 64-row tiles (tests)
         self.gn_fused_stats = int(_os.environ.get("SEVA_GN_FUSED_STATS", "1"))
         self._stats: dict = {}
         self.conv_splitk = _os.environ.get("SEVA_CONV_SPLITK", "1") != "0"  # 0: 64-row tiles at the 9x9 level (A/B runs)
@@ -272,18 +271,13 @@ class SevaEngine:
     # statistics pass over the fp32 tensor.  Only where a 64-row block cannot straddle two samples (hw % 64 == 0: results stay
     # bitwise independent of the batch composition) and where the launch keeps 128-row tiles anyway.
     def _stats_buf(self, name, rows, hw, c):
-        rows_per_block = ops.stats_rows_for(hw)  # 64, or 16 for images of hw % 16 == 0 pixels (36 x 36), or 0: keep the statistics pass
-        if not self.gn_fused_stats or not rows_per_block or c < 128 or c % 4:
-            return None
-        # 16-row blocks (36 x 36 images) are supported end to end but measured net zero at the headline shape (norm class -0.3 ms, conv
-        # and GEMM epilogues +0.3 ms per step: four times the cross-lane reductions): only under mode 2
-        if self.gn_fused_stats < 2 and rows_per_block != 64:
+        if not self.gn_fused_stats or hw % ops.STATS_ROWS or c < 128 or c % 4:
             return None
         # small images keep the statistics pass: their launches run 64-row tiles, which have no statistics variant.  The rule
         # looks at ONE sample (never at the batch size): a sample's result must not depend on what it is batched with
         if self.gn_fused_stats < 2 and (hw // 128) * ((c + 159) // 160) < 16:
             return None
-        return self._buf("st:" + name, ops.channel_stats_shape(rows, c, rows_per_block), F32)
+        return self._buf("st:" + name, ops.channel_stats_shape(rows, c), F32)
 
     def _sk(self, rows, hw, c):
         """Split-K workspace for the convs of small images (the 9x9 level): seva_gemm_desc.splitk_ws.  None elsewhere."""

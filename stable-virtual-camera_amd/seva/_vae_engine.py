@@ -88,14 +88,11 @@ class _VaeEngineBase:
 
     # GroupNorm statistics from the producing conv / GEMM epilogue (same scheme as seva/_engine.py:_stats_buf)
     def _stats_buf(self, name, rows, hw, c):
-        rows_per_block = ops.stats_rows_for(hw)  # 64, or 16 for images of hw % 16 == 0 pixels (36 x 36), or 0: keep the statistics pass
-        if not self.gn_fused_stats or not rows_per_block or c < 128 or c % 4:
-            return None
-        if self.gn_fused_stats < 2 and rows_per_block != 64:  # (16-row blocks: see seva/_engine.py)
+        if not self.gn_fused_stats or hw % ops.STATS_ROWS or c < 128 or c % 4:
             return None
         if self.gn_fused_stats < 2 and (hw // 128) * ((c + 159) // 160) < 16:  # per sample, never per batch
             return None
-        return self._buf("st:" + name, ops.channel_stats_shape(rows, c, rows_per_block), F32)
+        return self._buf("st:" + name, ops.channel_stats_shape(rows, c), F32)
 
     def _produced(self, out, st):
         if st is None:

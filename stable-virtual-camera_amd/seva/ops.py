@@ -64,7 +64,7 @@ def gemm(
     d.rows_per_group, d.ld_row_add = rows_per_group, ld_row_add
     d.mode, d.epilogue = 0, 1 if geglu else 0
     d.col_scale, d.col_scale_n = col_scale, col_scale_n
-    d.ch_stats, d.ch_stats_rows = _stats_ptr(ch_stats, M, N, out_f32)
+    d.ch_stats = _stats_ptr(ch_stats, M, N, out_f32)
     if fp8:
         assert w_exp.dtype == U8 and w_exp.numel() == N and (out_f8 is None or out_f8.dtype == U8)
         d.w_exp, d.out_f8 = w_exp.data_ptr(), ptr(out_f8)
@@ -75,17 +75,12 @@ def gemm(
         check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(a.device)), "seva_gemm_f16")
 
 
-STATS_ROWS = 64  # default rows per block of the epilogue-emitted GroupNorm statistics (include/seva_hip.h: seva_gemm_desc.ch_stats)
+STATS_ROWS = 64  # rows per block of the epilogue-emitted GroupNorm statistics (include/seva_hip.h: seva_gemm_desc.ch_stats)
 
 
-def stats_rows_for(hw: int) -> int:
-    """Block height under which a block never straddles two samples of `hw` pixels: 64, 16, or 0 (no producer statistics)."""
-    return 64 if hw % 64 == 0 else 16 if hw % 16 == 0 else 0
-
-
-def channel_stats_shape(rows: int, channels: int, stats_rows: int = STATS_ROWS) -> tuple[int, int, int]:
+def channel_stats_shape(rows: int, channels: int) -> tuple[int, int, int]:
     """Shape of the f32 buffer a GEMM / conv fills through `ch_stats`: [row blocks][sum | sum of squares][channel]."""
-    return ((rows + stats_rows - 1) // stats_rows, 2, channels)
+    return ((rows + STATS_ROWS - 1) // STATS_ROWS, 2, channels)
 
 
 def splitk_workspace(max_rows: int, max_channels: int, device) -> torch.Tensor:
@@ -95,14 +90,11 @@ def splitk_workspace(max_rows: int, max_channels: int, device) -> torch.Tensor:
 
 
 def _stats_ptr(ch_stats, M, N, out_f32):
-    """ch_stats: a buffer of `channel_stats_shape`; its first dim tells the block height (ceil(M / 64) or ceil(M / 16))."""
     if ch_stats is None:
-        return None, 0
-    assert out_f32 is not None and ch_stats.dtype == F32 and ch_stats.is_contiguous() and ch_stats.dim() == 3
-    nb = ch_stats.shape[0]
-    rows = 64 if nb == (M + 63) // 64 else 16
-    assert nb == (M + rows - 1) // rows and ch_stats.shape[1] == 2 and ch_stats.shape[2] == N
-    return ch_stats.data_ptr(), rows
+        return None
+    assert out_f32 is not None and ch_stats.dtype == F32 and ch_stats.is_contiguous()
+    assert ch_stats.numel() >= ((M + STATS_ROWS - 1) // STATS_ROWS) * 2 * N
+    return ch_stats.data_ptr()
 
 
 FF_FUSED_CHANNELS = (64, 128, 256, 320)
@@ -175,7 +167,7 @@ def conv3x3(
     d.n, d.ih, d.iw, d.cin, d.oh, d.ow = n, ih, iw, cin, oh, ow
     d.stride, d.upsample = stride, 1 if upsample else 0
     d.pad_br_only = 1 if pad_br_only else 0
-    d.ch_stats, d.ch_stats_rows = _stats_ptr(ch_stats, n * oh * ow, w.shape[0], out_f32)
+    d.ch_stats = _stats_ptr(ch_stats, n * oh * ow, w.shape[0], out_f32)
     if splitk_ws is not None and not fp8:  # `splitk_workspace`: lets small-image convs run as split-K = 2 (seva_hip.h)
         assert splitk_ws.dtype == F32 and splitk_ws.is_contiguous()
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * 4
@@ -267,11 +259,10 @@ def groupnorm(
     d.silu, d.eps = 1 if silu else 0, eps
     d.raw_f16 = ptr(raw_f16)
     if stats1 is not None:
-        rows = 64 if stats1.shape[0] == (n * hw + 63) // 64 else 16
-        assert hw % rows == 0 and (x2 is None) == (stats2 is None)
-        assert stats1.dtype == F32 and tuple(stats1.shape) == (n * hw // rows, 2, c1)
-        assert stats2 is None or (stats2.dtype == F32 and tuple(stats2.shape) == (n * hw // rows, 2, c2))
-        d.stats1, d.stats2, d.stats_rows = stats1.data_ptr(), ptr(stats2), rows
+        assert hw % STATS_ROWS == 0 and (x2 is None) == (stats2 is None)
+        assert stats1.dtype == F32 and stats1.numel() >= (n * hw // STATS_ROWS) * 2 * c1
+        assert stats2 is None or (stats2.dtype == F32 and stats2.numel() >= (n * hw // STATS_ROWS) * 2 * c2)
+        d.stats1, d.stats2 = stats1.data_ptr(), ptr(stats2)
     else:
         assert stats2 is None
     assert raw_f16 is None or (raw_f16.dtype == F16 and raw_f16.is_contiguous() and raw_f16.numel() == n * hw * (c1 + c2))

@@ -38,24 +38,18 @@ def splitk_workspace(max_rows, max_channels, device):
     return torch.zeros(16, dtype=F32)
 
 
-def stats_rows_for(hw):
-    return 64 if hw % 64 == 0 else 16 if hw % 16 == 0 else 0
-
-
-def channel_stats_shape(rows, channels, stats_rows=STATS_ROWS):
-    return ((rows + stats_rows - 1) // stats_rows, 2, channels)
+def channel_stats_shape(rows, channels):
+    return ((rows + STATS_ROWS - 1) // STATS_ROWS, 2, channels)
 
 
 def _emit_stats(acc, ch_stats):
     """seva_gemm_desc.ch_stats: per 64-row block and channel, sum and sum of squares of the fp32 output."""
     M, N = acc.shape
-    R = 64 if ch_stats.shape[0] == (M + 63) // 64 else 16
-    nb = (M + R - 1) // R
-    assert tuple(ch_stats.shape) == (nb, 2, N)
-    pad = torch.zeros((nb * R, N), dtype=F32)
+    nb = (M + STATS_ROWS - 1) // STATS_ROWS
+    pad = torch.zeros((nb * STATS_ROWS, N), dtype=F32)
     pad[:M] = acc
-    blk = pad.view(nb, R, N)
-    st = ch_stats
+    blk = pad.view(nb, STATS_ROWS, N)
+    st = ch_stats.view(-1)[: nb * 2 * N].view(nb, 2, N)
     st[:, 0] = blk.sum(1)
     st[:, 1] = (blk * blk).sum(1)
 
@@ -179,13 +173,11 @@ def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, s
         # statistics come from the producers' epilogues (seva_groupnorm_desc.stats1 / stats2): USE them, so that a wrong or
         # stale buffer handed over by the engine shows up as a wrong result
         n, hw = x.shape[0], x.shape[1]
-        R = 64 if stats1.shape[0] == (n * hw + 63) // 64 else 16
-        assert hw % R == 0 and (x2 is None) == (stats2 is None) and stats1.shape[0] == n * hw // R
-        nb = hw // R
-        parts = [stats1.view(n, nb, 2, x1.shape[-1])]
+        assert hw % STATS_ROWS == 0 and (x2 is None) == (stats2 is None)
+        nb = hw // STATS_ROWS
+        parts = [stats1.view(-1)[: n * nb * 2 * x1.shape[-1]].view(n, nb, 2, x1.shape[-1])]
         if x2 is not None:
-            assert stats2.shape[0] == n * hw // R
-            parts.append(stats2.view(n, nb, 2, x2.shape[-1]))
+            parts.append(stats2.view(-1)[: n * nb * 2 * x2.shape[-1]].view(n, nb, 2, x2.shape[-1]))
         st = torch.cat(parts, -1).double().sum(1)  # [n, 2, C]
         cnt = hw * (C // groups)
         mean = st[:, 0].view(n, groups, -1).sum(-1) / cnt
