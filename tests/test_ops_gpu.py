@@ -253,7 +253,7 @@ def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, knobs):
     the key sequence, keys that beat the running maximum by far more than the deferred-rescale threshold
     (rescale branch), and shifts all logits of the first tile far below zero (first-tile reference)."""
     from seva import ops
-    knobs(attn_two=two)  # 1: the opt-in two-chain kernel for Lq >= 512
+    knobs(attn_two=two)  # 0: attn_kernel everywhere, 1: the two-query-block kernel from Lq >= 512, 3: the software-pipelined kernel
     C = 64 * H
     g = torch.Generator().manual_seed(31)
     q = torch.randn((B, Lq, H, 64), generator=g)
