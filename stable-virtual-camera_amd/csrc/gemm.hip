@@ -574,8 +574,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) *(f32x4*)(part + (i * NJ + j) * 1024) = acc[i][j];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's stores are visible device-wide ...
+            for (int j = 0; j < NJ; ++j) st_coherent_x4(part + (i * NJ + j) * 1024, acc[i][j]);  // (no L2-wide fence: gemm_common.h)
+          wait_vm0();                                         // this thread's device-coherent stores are acknowledged ...
           __syncthreads();                                    // ... for every thread of the workgroup ...
           if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... then the flag
           continue;  // no epilogue: the partner finishes the tile
@@ -592,11 +592,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch / graph replay
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        {
+          f32x4 pt[NJ];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i) {
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] += *(const f32x4*)(part + (i * NJ + j) * 1024);
+            for (int j = 0; j < NJ; ++j) pt[j] = ld_coherent_x4(part + (i * NJ + j) * 1024);
+            wait_vm0();
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(pt[j]));  // no read of the asm loads' destinations may move above the wait
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] += pt[j];
+          }
+        }
       }
     }
     // ASYNC bookkeeping: S_ST is exact only for an interior tile (every guarded store executes) with
@@ -1025,6 +1033,24 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   // 5-25 % slower: profiles/r01_kbench_bn64.log.)  SEVA_GEMM_BN=128|160 forces the width (benchmark knob).
   bool wide = d->N % 160 == 0;
   if (g_seva_knobs.gemm_bn > 0) wide = g_seva_knobs.gemm_bn == 160;
+  // Stream-K (gemm_sk.hip) for fp32-output launches whose 128-row tile count leaves the last round of the 512 workgroup slots
+  // partly empty (18 x 18 level: 856 tiles = 1.67 rounds).  Bitwise equal to the unsplit kernel -- and SLOWER on every shape of
+  // this network (-1 ... -23 %, tools/kstreamk.py): equal K-ranges desynchronise the sibling tiles that otherwise stream one A
+  // panel through an XCD's L2 in step, and that costs more than the partly empty round.  Opt-in only (knob gemm_streamk = 1).
+  if (d->splitk_ws && !a.sk_ws && !half_m && !narrow && d->out_f32 && d->col_scale_n == 0 && !d->upsample &&
+      g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_chunks <= 0 && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0 &&
+      g_seva_knobs.gemm_cfg <= 0 && g_seva_knobs.gemm_streamk != 0) {
+    const int bn = wide ? 160 : 128, P = 512;
+    const int64_t tm = (d->M + 127) / 128, tn = (d->N + bn - 1) / bn, T = tm * tn, rem = T % P;
+    (void)rem;
+    if (g_seva_knobs.gemm_streamk == 1 && T >= P && a.K / BK >= 8 &&
+        d->splitk_ws_bytes >= (int64_t)(16384 + (int64_t)P * 128 * bn) * 4 && (uintptr_t)d->splitk_ws % 16 == 0) {
+      a.sk_ws = d->splitk_ws;
+      a.tiles_m = (int)tm;
+      a.tiles_n = (int)tn;
+      return seva_gemm_streamk_launch(a, d->mode, bn, P, s);
+    }
+  }
   if (d->mode == 0) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
     if (half_m) return wide ? launch<64, 160, 0, 0>(a, s) : launch<64, 128, 0, 0>(a, s);

@@ -54,6 +54,21 @@ static __device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds
       : "memory");
 }
 
+// Workgroup-to-workgroup hand-off of raw accumulator tiles (split-K / stream-K): device-coherent (sc1 = agent scope) 16-byte stores and
+// loads, which go past the XCD-private L2 instead of an agent-scope release / acquire FENCE around plain accesses -- a fence
+// writes back / invalidates the WHOLE L2 of the XCD, and with one per workgroup the operand panels of every other workgroup
+// on that XCD kept being evicted (stream-K measured 25 % slower than the unsplit kernel with fences).  Protocol: sc1 payload
+// stores -> s_waitcnt vmcnt(0) -> barrier -> sc1 flag store;  sc1 flag load (spin) -> barrier -> sc1 payload loads.
+static __device__ __forceinline__ void st_coherent_x4(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+static __device__ __forceinline__ f32x4 ld_coherent_x4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+static __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Bijective XCD-aware remap (blocks b, b+8, ... share an XCD): each XCD gets one contiguous run of
 // logical tiles, so the A row-panel it streams is fetched into that XCD's L2 once.
 static __device__ __forceinline__ int xcd_remap(int bid, int nb) {
@@ -62,6 +77,8 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   return start + (bid >> 3);
 }
 
+// gemm_sk.hip: stream-K variant of the plain f32-output kernel (a.tiles_m / a.tiles_n for 128 x bn tiles, a.sk_ws set)
+int seva_gemm_streamk_launch(const GemmArgs& a, int mode, int bn, int nblocks, hipStream_t s);
 // gemm_ring.hip: cfg 1 = 256x128x64 (3 stages), cfg 2 = 256x256x32 (4 stages), cfg 3 = 128x128x32 (4 stages)
 int seva_gemm_ring_launch(const GemmArgs& a, int mode, int epilogue, int cfg, hipStream_t s);
 // gemm_phase.hip: 256x256x64, two wave groups in anti-phase (cfg 4)

@@ -279,12 +279,13 @@ class SevaEngine:
             return None
         return self._buf("st:" + name, ops.channel_stats_shape(rows, c), F32)
 
-    def _sk(self, rows, hw, c):
-        """Split-K workspace for the convs of small images (the 9x9 level): seva_gemm_desc.splitk_ws.  None elsewhere."""
-        if not self.conv_splitk or hw > 128:
+    def _sk(self, rows=0, hw=0, c=0):
+        """Workspace of seva_gemm_desc.splitk_ws (one per engine; its launches are serialised on one stream): lets the library run
+        the convs of small images (the 9x9 level) as split-K (and, under the knob gemm_streamk = 1, the convs of the 18x18 / 36x36 levels
+        as stream-K: measured slower).  16384 flags + 512 slots of 128 x 160 floats (>= every split-K need here)."""
+        if not self.conv_splitk:
             return None
-        shape = (16384 + ((rows + 127) // 128) * ((c + 127) // 128) * 128 * 160,)
-        return self._buf("sk_ws", shape, F32, zero=True)
+        return self._buf("sk_ws", (16384 + 512 * 128 * 160,), F32, zero=True)
 
     def _produced(self, out, st):
         """Record (or forget) the statistics buffer that travels with fp32 tensor `out`."""

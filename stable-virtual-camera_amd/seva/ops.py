@@ -40,8 +40,10 @@ def gemm(
     w_exp: torch.Tensor | None = None,
     out_f8: torch.Tensor | None = None,
     ch_stats: torch.Tensor | None = None,
+    splitk_ws: torch.Tensor | None = None,
 ) -> None:
     """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16).
+    splitk_ws (`splitk_workspace`): lets fp32-output launches with a partly filled last round of workgroup slots run as stream-K.
     ch_stats (`channel_stats_buffer`): receives per-64-row-block, per-channel sum / sum of squares of out_f32 (GroupNorm
     statistics emitted by the epilogue; `groupnorm(stats1=...)`).
     Output features < col_scale_n are multiplied by col_scale in fp32 (plain epilogue only).
@@ -65,6 +67,9 @@ def gemm(
     d.mode, d.epilogue = 0, 1 if geglu else 0
     d.col_scale, d.col_scale_n = col_scale, col_scale_n
     d.ch_stats = _stats_ptr(ch_stats, M, N, out_f32)
+    if splitk_ws is not None and not fp8:
+        assert splitk_ws.dtype == F32 and splitk_ws.is_contiguous()
+        d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * 4
     if fp8:
         assert w_exp.dtype == U8 and w_exp.numel() == N and (out_f8 is None or out_f8.dtype == U8)
         d.w_exp, d.out_f8 = w_exp.data_ptr(), ptr(out_f8)
@@ -85,7 +90,7 @@ def channel_stats_shape(rows: int, channels: int) -> tuple[int, int, int]:
 
 def splitk_workspace(max_rows: int, max_channels: int, device) -> torch.Tensor:
     """Zeroed workspace for `conv3x3(splitk_ws=...)`: 16384 flags + one fp32 128 x 160 tile per output tile."""
-    tiles = ((max_rows + 127) // 128) * ((max_channels + 127) // 128)
+    tiles = max(512, ((max_rows + 127) // 128) * ((max_channels + 127) // 128))  # (stream-K: one slot per workgroup, 512 of them)
     return torch.zeros(16384 + tiles * 128 * 160, dtype=F32, device=device)
 
 

@@ -42,7 +42,7 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-KNOB_NAMES = ("gemm_chunks", "gemm_dbg", "gemm_stagger", "gemm_cfg", "gemm_bm", "gemm_bn", "gemm_astat",
+KNOB_NAMES = ("gemm_chunks", "gemm_dbg", "gemm_stagger", "gemm_cfg", "gemm_bm", "gemm_bn", "gemm_astat", "gemm_streamk",
               "attn_dbg", "attn_no_tr", "attn_two", "gn_min_iter", "ff_variant")
 
 
