@@ -93,7 +93,9 @@ typedef struct seva_gemm_desc {
    * sample, K >= 1024: the 9x9 level of a 576x576 step) as split-K = 2 on 128-row tiles: two workgroups per tile, the
    * upper half of K exported raw, added by the partner before the epilogue (fixed association: deterministic, and chosen
    * from per-sample dimensions only).  Layout: 16384 int flags (zero before first use; every launch leaves them zero), then
-   * one 128 x BN fp32 tile per output tile: splitk_ws_bytes >= 4 * (16384 + tiles * 128 * 160).  One launch at a time may
+   * one 128 x BN fp32 tile per output tile: splitk_ws_bytes >= 4 * (16384 + max(tiles, 512) * 128 * 160) (512 slots serve the
+   * opt-in stream-K kernel, knob gemm_streamk = 1, which fp32-output GEMMs and convs of >= 512 tiles then use).  The hand-off
+   * uses agent-scope (sc1) stores / loads, no cache-wide fence.  One launch at a time may
    * use a given workspace (launches on ONE stream are fine). */
   float* splitk_ws;
   int64_t splitk_ws_bytes;
