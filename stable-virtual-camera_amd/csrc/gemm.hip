@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) st_coherent_x4(part + (i * NJ + j) * 1024, acc[i][j]);  // (no L2-wide fence: gemm_common.h)
-          wait_vm0();                                         // this thread's device-coherent stores are acknowledged ...
+          publish_coherent();                                 // this thread's stores are visible device-wide ...
           __syncthreads();                                    // ... for every thread of the workgroup ...
           if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... then the flag
           continue;  // no epilogue: the partner finishes the tile
@@ -598,9 +598,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) pt[j] = ld_coherent_x4(part + (i * NJ + j) * 1024);
-            wait_vm0();
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(pt[j]));  // no read of the asm loads' destinations may move above the wait
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] += pt[j];
           }

@@ -54,20 +54,32 @@ static __device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds
       : "memory");
 }
 
-// Workgroup-to-workgroup hand-off of raw accumulator tiles (split-K / stream-K): device-coherent (sc1 = agent scope) 16-byte stores and
-// loads, which go past the XCD-private L2 instead of an agent-scope release / acquire FENCE around plain accesses -- a fence
-// writes back / invalidates the WHOLE L2 of the XCD, and with one per workgroup the operand panels of every other workgroup
-// on that XCD kept being evicted (stream-K measured 25 % slower than the unsplit kernel with fences).  Protocol: sc1 payload
-// stores -> s_waitcnt vmcnt(0) -> barrier -> sc1 flag store;  sc1 flag load (spin) -> barrier -> sc1 payload loads.
-static __device__ __forceinline__ void st_coherent_x4(float* p, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+// Workgroup-to-workgroup hand-off of raw accumulator tiles (split-K / stream-K): agent-scope (sc1) relaxed atomic dword stores and
+// loads, which go past the XCD-private L2.  Protocol: sc1 payload stores -> s_waitcnt vmcnt(0) -> barrier -> sc1 flag store;
+// sc1 flag load (spin) -> barrier -> sc1 payload loads.  Two things that were tried and are NOT done:
+//  * an agent-scope release / acquire FENCE pair around plain accesses: a fence writes back / invalidates the whole L2 of the
+//    XCD, and with one per workgroup the operand panels of every other workgroup on that XCD kept being evicted (stream-K ran
+//    25 % slower than the unsplit kernel; even the producer-side release alone cost the split-K path its whole gain);
+//  * hand-written `global_load_dwordx4 ... sc1` asm for the payload: hipcc moved the destination registers before the
+//    hand-placed wait and a few 16-byte pieces (sometimes garbage) reached the accumulators -- only when successive launches
+//    sent DIFFERENT data through the workspace (tools/sk_repro.py).  These are compiler-tracked.
+static __device__ __forceinline__ void st_coherent_x4(float* p, f32x4 v) {  // four agent-scope (sc1) dword stores
+#pragma unroll
+  for (int r = 0; r < 4; ++r) __hip_atomic_store(p + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-static __device__ __forceinline__ f32x4 ld_coherent_x4(const float* p) {
+static __device__ __forceinline__ f32x4 ld_coherent_x4(const float* p) {  // four agent-scope (sc1) dword loads, compiler-tracked
   f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = __hip_atomic_load(p + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return v;
 }
-static __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+static __device__ __forceinline__ void publish_coherent() {  // after the payload stores, before the barrier that precedes the flag
+#ifdef SEVA_HANDOFF_RELEASE_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // L2 write-back + wait
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the agent-scope stores of this thread are acknowledged
+#endif
+}
 
 // Bijective XCD-aware remap (blocks b, b+8, ... share an XCD): each XCD gets one contiguous run of
 // logical tiles, so the A row-panel it streams is fetched into that XCD's L2 once.

@@ -166,11 +166,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(GemmArgs p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = ld_coherent_x4(part + (i * NJ + jj) * 1024);
-      wait_vm0();  // (asm loads: the compiler does not track them; this also retires stage kb, which the barrier below needs anyway)
-#pragma unroll
-      for (int i = 0; i < MI; ++i)  // ... and nothing may read the destination registers above that wait: re-define them after it
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) asm volatile("" : "+v"(acc[i][jj]));
+
     } else if (p.residual) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -219,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(GemmArgs p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) st_coherent_x4(part + (i * NJ + jj) * 1024, acc[i][jj]);
-      wait_vm0();  // this thread's device-coherent stores are acknowledged
+      publish_coherent();  // this thread's stores are visible device-wide
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;

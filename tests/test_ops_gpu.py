@@ -518,40 +518,51 @@ def test_conv_splitk_small_images(dev, n, ih, iw, cin, cout, stride):
 @pytest.mark.parametrize("kind,shape", [("gemm", (13608, 1280, 5120)), ("gemm", (54432, 640, 2560)), ("gemm", (13608, 1280, 1280)),
                                         ("gemm", (70000, 256, 512)), ("conv", (42, 18, 18, 1280, 1280, 1)),
                                         ("conv", (42, 36, 36, 640, 640, 1)), ("conv", (42, 36, 36, 640, 1280, 2)),
-                                        ("conv", (21, 40, 24, 128, 384, 1))])
+                                        ("conv", (21, 40, 24, 128, 384, 1)), ("conv", (16, 72, 72, 64, 320, 1)),
+                                        ("conv", (16, 72, 72, 320, 320, 1))])
 def test_streamk_bitwise_equal_to_unsplit(dev, kind, shape, knobs):
     """Stream-K (gemm_sk.hip: a tile that straddles two workgroups' ranges is CONTINUED from the exported accumulators) gives
     bitwise the output and the epilogue statistics of the unsplit kernel on random data, with bias + row_add + residual; the
-    workspace flags are left zero, the error slot stays 0, and a second launch through the same workspace agrees."""
+    workspace flags are left zero, the error slot stays 0.  Two DIFFERENT data sets alternate through ONE workspace (a hand-off
+    that read stale or early data would go unnoticed if every launch wrote the same partial tiles)."""
     from seva import ops
     from seva._engine import pack_conv3x3
-    if kind == "gemm":
-        M, N, K = shape
-        a = _rand((M, K), dev, 1).half()
-        w = _rand((N, K), dev, 2, 0.05).half()
-        rpg = 324
-        call = lambda o, st, ws: ops.gemm(a, w, bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o, ch_stats=st,
-                                          splitk_ws=ws)
-    else:
-        n, ih, iw, cin, N, stride = shape
-        oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
-        M, rpg = n * oh * ow, oh * ow
-        x = _rand((n, ih, iw, cin), dev, 1).half()
-        w = pack_conv3x3(_rand((N, cin, 3, 3), dev, 2, 0.05)).half()
-        call = lambda o, st, ws: ops.conv3x3(x, w, stride=stride, bias=bias, row_add=radd, rows_per_group=rpg, residual=res,
-                                             out_f32=o, ch_stats=st, splitk_ws=ws)
-    bias, res = _rand((N,), dev, 3), _rand((M, N), dev, 4)
-    radd = _rand(((M + rpg - 1) // rpg, N), dev, 5)
+
+    def case(seed):
+        if kind == "gemm":
+            M, N, K = shape
+            a = _rand((M, K), dev, seed).half()
+            w = _rand((N, K), dev, seed + 1, 0.05).half()
+            rpg = 324
+            fn = lambda o, st, ws: ops.gemm(a, w, bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o, ch_stats=st,
+                                            splitk_ws=ws)
+        else:
+            n, ih, iw, cin, N, stride = shape
+            oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
+            M, rpg = n * oh * ow, oh * ow
+            x = _rand((n, ih, iw, cin), dev, seed).half()
+            w = pack_conv3x3(_rand((N, cin, 3, 3), dev, seed + 1, 0.05)).half()
+            fn = lambda o, st, ws: ops.conv3x3(x, w, stride=stride, bias=bias, row_add=radd, rows_per_group=rpg, residual=res,
+                                               out_f32=o, ch_stats=st, splitk_ws=ws)
+        bias, res = _rand((N,), dev, seed + 2), _rand((M, N), dev, seed + 3)
+        radd = _rand(((M + rpg - 1) // rpg, N), dev, seed + 4)
+        return fn, M, N
+
+    (fa, M, N), (fb, _, _) = case(1), case(101)
     ws = ops.splitk_workspace(M, N, dev)
-    o_ref, st_ref = torch.empty((M, N), device=dev), torch.empty(ops.channel_stats_shape(M, N), device=dev)
+    refs = []
     knobs(gemm_streamk=0)
-    call(o_ref, st_ref, ws)
-    knobs(gemm_streamk=1)  # forced wherever eligible (the default rule only takes launches with a partly filled last round)
-    for _ in range(2):
+    for fn in (fa, fb):
+        o_ref, st_ref = torch.empty((M, N), device=dev), torch.empty(ops.channel_stats_shape(M, N), device=dev)
+        fn(o_ref, st_ref, ws)
+        refs.append((o_ref, st_ref))
+    knobs(gemm_streamk=1)  # forced wherever eligible
+    for it in range(6):
+        fn, (o_ref, st_ref) = (fa, fb)[it & 1], refs[it & 1]
         o = torch.full((M, N), float("nan"), device=dev)
         st = torch.full_like(st_ref, float("nan"))
-        call(o, st, ws)
-        assert torch.equal(o, o_ref), f"max diff {(o - o_ref).abs().max()}"
+        fn(o, st, ws)
+        assert torch.equal(o, o_ref), f"launch {it}: max diff {(o - o_ref).abs().max()}"
         assert torch.equal(st, st_ref)
         assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
 
