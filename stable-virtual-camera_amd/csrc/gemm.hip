@@ -1023,7 +1023,16 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     a.sk_ws = d->splitk_ws;
     half_m = false;
   }
-  if (d->epilogue == 1) return half_m ? launch<64, 128, 0, 1>(a, s) : launch<128, 128, 0, 1>(a, s);
+  if (d->epilogue == 1) {
+    // GEGLU tiles are 128 wide (the epilogue pairs 64-row value / gate groups), so the cheaper operand stream comes from the
+    // other side: 160 x 128 tiles -- 10 % fewer LDS-DMA bytes per FLOP, 40 instead of 32 MFMAs per wave and barrier, 215
+    // registers, still two workgroups per CU.  Bitwise the same outputs; ds2 / ds4 -6 %, the 9x9 level -15 % against its 64-row
+    // tiles (tools/kgeglu_bm.py).  K <= 320 keeps the A-in-registers kernel (a 128-row design).
+    const bool dbg_run = g_seva_knobs.gemm_dbg >= 0 || g_seva_knobs.gemm_stagger >= 0;
+    const bool tall = g_seva_knobs.gemm_bm == 160 || (g_seva_knobs.gemm_bm <= 0 && !dbg_run && d->K > 320 && d->M >= 1024);
+    if (tall) return launch_p<160, 128, 0, 1, true>(a, s);
+    return half_m ? launch<64, 128, 0, 1>(a, s) : launch<128, 128, 0, 1>(a, s);
+  }
   // 128x160 tiles: every channel count of the network (320 .. 10240) is a multiple of 160, so no MFMA
   // column is idle (N = 320: 2 tiles instead of 3 with the last half empty), and a tile needs 10 %
   // fewer LDS-DMA bytes and fragment reads per FLOP than 128x128.  (128x64 tiles, tried earlier, were

@@ -169,6 +169,30 @@ def test_gemm_geglu(dev, M, C):
     assert rel_l2(o16, ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,C,K", [(1000, 640, 640), (2049, 320, 1280), (1600, 128, 704), (4000, 1280, 1280)])
+def test_geglu_tile_heights_bitwise_equal(dev, M, C, K, knobs):
+    """GEGLU GEMM on 160 x 128 tiles (the default for K > 320, M >= 1024), 128 x 128 and 64 x 128 tiles: the same bits (a row's
+    dot products do not depend on the tile it falls in), M tails against every height, f16 and f32 outputs; and right."""
+    from seva import ops
+    from seva._engine import interleave_geglu
+    a = _rand((M, K), dev, 81).half()
+    w = (_rand((8 * C, K), dev, 82) * K ** -0.5).half()
+    b = _rand((8 * C,), dev, 83)
+    wi, bi = interleave_geglu(w, b)
+    outs = []
+    for bm in (160, 128, 64, -1):
+        knobs(gemm_bm=bm)
+        o16 = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.float16)
+        o32 = torch.full((M, 4 * C), float("nan"), device=dev)
+        ops.gemm(a, wi, bias=bi, out_f16=o16, out_f32=o32, geglu=True)
+        outs.append((o16, o32))
+    for o16, o32 in outs[1:]:
+        assert torch.equal(o16, outs[0][0]) and torch.equal(o32, outs[0][1])
+    y = a.float() @ w.float().T + b
+    ref = y[:, : 4 * C] * F.gelu(y[:, 4 * C:])
+    assert rel_l2(outs[0][1], ref) < 3e-6 and rel_l2(outs[0][0], ref) < 1e-3
+
+
 CONV_CASES = [  # n, ih, iw, cin, cout, stride, upsample
     (2, 9, 9, 64, 64, 1, False), (3, 16, 12, 128, 96, 1, False), (2, 16, 12, 64, 64, 2, False),
     (2, 9, 7, 64, 128, 2, False), (2, 8, 6, 64, 64, 1, True), (1, 5, 5, 192, 4, 1, False),
