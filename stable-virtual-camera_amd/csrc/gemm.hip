@@ -989,6 +989,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     if (d->ch_stats) half_m8 = false;  // statistics are emitted per wave-owned 64-row block: 128-row tiles only
     bool wide8 = d->N % 160 == 0;
     if (g_seva_knobs.gemm_bn > 0) wide8 = g_seva_knobs.gemm_bn == 160;
+    // (160-row GEGLU tiles, the f16 default, were measured here too: 255 registers with a small spill, no gain)
     if (d->epilogue == 1) return half_m8 ? launch<64, 128, 0, 1, true>(a, s) : launch<128, 128, 0, 1, true>(a, s);
     // 128-row tiles are 128 wide only: 128x160 with both k-steps' fragments live exceeds 256 VGPRs (spills)
     if (d->mode == 0) {
