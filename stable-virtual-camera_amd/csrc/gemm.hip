@@ -1058,6 +1058,19 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
       return seva_gemm_streamk_launch(a, d->mode, bn, P, s);
     }
   }
+  // 160 x 160 tiles for the fp32-output kernels (not the f16-only ASYNC ones: their bias slots would not fit): 0.0125 operand bytes
+  // per FLOP instead of 0.0141, 50 instead of 40 MFMAs per wave and barrier; two workgroups take EXACTLY the CU's 160 KiB of LDS
+  // and all 256 registers (no spill in GEMM mode, 7 dwords in conv mode).  Bitwise the same outputs; -3 ... -10 % on every shape
+  // measured, also where 160-row tiles quantise worse (tools/ktile160.py).  Launches that emit GroupNorm statistics keep 128
+  // rows (a wave must own a 64-row block), as do the small ones (64-row tiles / split-K) and the fused-upsample conv.
+  {
+    const bool dbg_run = g_seva_knobs.gemm_dbg >= 0 || g_seva_knobs.gemm_stagger >= 0;
+    const bool f16_only = d->mode == 0 && d->out_f16 && !d->out_f32 && !d->residual;
+    const bool big = g_seva_knobs.gemm_bm == 160 ||
+                     (g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0 && !dbg_run && !half_m && d->M >= 2048);
+    if (big && wide && !narrow && !d->ch_stats && !d->upsample && !a.sk_ws && !f16_only)
+      return d->mode == 0 ? launch_p<160, 160, 0, 0, false>(a, s) : launch_p<160, 160, 1, 0, false>(a, s);
+  }
   if (d->mode == 0) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
     if (half_m) return wide ? launch<64, 160, 0, 0>(a, s) : launch<64, 128, 0, 0>(a, s);

@@ -193,6 +193,37 @@ def test_geglu_tile_heights_bitwise_equal(dev, M, C, K, knobs):
     assert rel_l2(outs[0][1], ref) < 3e-6 and rel_l2(outs[0][0], ref) < 1e-3
 
 
+@pytest.mark.parametrize("kind,shape", [("gemm", (3000, 640, 640)), ("gemm", (2049, 320, 1280)), ("gemm", (5000, 1280, 192)),
+                                        ("conv", (9, 18, 18, 128, 320, 1)), ("conv", (8, 36, 36, 64, 640, 2)), ("conv", (3, 40, 24, 192, 160, 1))])
+def test_tile_160x160_bitwise_equal(dev, kind, shape, knobs):
+    """fp32-output GEMM / conv on 160 x 160 tiles (the default from M >= 2048 when N % 160 == 0 and no statistics are emitted) vs
+    128 x 160 and 64 x 160 tiles: the same bits, with bias + row_add + residual and M tails against every height."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    if kind == "gemm":
+        M, N, K = shape
+        a, w = _rand((M, K), dev, 1).half(), _rand((N, K), dev, 2, 0.05).half()
+        rpg = 100
+        fn = lambda o: ops.gemm(a, w, bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o)
+    else:
+        n, ih, iw, cin, N, stride = shape
+        oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
+        M, rpg = n * oh * ow, oh * ow
+        x, w = _rand((n, ih, iw, cin), dev, 1).half(), pack_conv3x3(_rand((N, cin, 3, 3), dev, 2, 0.05)).half()
+        fn = lambda o: ops.conv3x3(x, w, stride=stride, bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o)
+    bias, res = _rand((N,), dev, 3), _rand((M, N), dev, 4)
+    radd = _rand(((M + rpg - 1) // rpg, N), dev, 5)
+    outs = []
+    for bm in (160, 128, 64, -1):
+        knobs(gemm_bm=bm)
+        o = torch.full((M, N), float("nan"), device=dev)
+        fn(o)
+        outs.append(o)
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 CONV_CASES = [  # n, ih, iw, cin, cout, stride, upsample
     (2, 9, 9, 64, 64, 1, False), (3, 16, 12, 128, 96, 1, False), (2, 16, 12, 64, 64, 2, False),
     (2, 9, 7, 64, 128, 2, False), (2, 8, 6, 64, 64, 1, True), (1, 5, 5, 192, 4, 1, False),
