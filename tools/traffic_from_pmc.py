@@ -17,7 +17,7 @@ import sys
 import re
 
 # kernel names: gemm_kernel<BM, BN, MODE, EPI, DBG> (MODE 0 plain / 1 conv3x3), attn_kernel<NW, KT, ...>
-CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128), (128|160), 0, |ff_fused"), "conv": re.compile(r"gemm_kernel<(64|128), (128|160), [12], "),
+CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128|160), (128|160), 0, |gemm_sk_kernel<\d+, 0>|ff_fused"), "conv": re.compile(r"gemm_kernel<(64|128|160), (128|160), [12], |gemm_sk_kernel<\d+, [12]>"),
            "attention": re.compile(r"attn_kernel<4, 64|attn2_kernel|attn3_kernel")}
 
 
