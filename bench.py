@@ -196,14 +196,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU.  Rehearsal on a one-GPU box only: SEVA_BENCH_DEVICE pins every rank to one card and
+    # SEVA_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); the numbers of such a run mean nothing.
+    dev_index = int(os.environ.get("SEVA_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SEVA_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # bound to this rank's card before the first collective
+        else:
+            dist.init_process_group(backend)
 
     from seva import _native, ops
     from seva.distributed import exchange_anchor_latents
@@ -368,6 +375,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 alone ran the VAE / CPU legs: nobody tears the communicator down under it
         dist.destroy_process_group()
 
 
