@@ -169,8 +169,11 @@ __global__ __launch_bounds__(256) void gn_finalize_ch_kernel(GnArgs p) {
   f[1] = (float)(1.0 / sqrt(var + (double)p.eps));
 }
 
-template <bool DENSE>
+// DC6: the modulation has exactly 6 components (the Pluecker maps -- every modulated GroupNorm of the network): weight pairs and
+// loops are sized for 6 at compile time (48 instead of 64 registers of weights, 6 instead of 8 packed FMAs per channel)
+template <bool DENSE, bool DC6 = false>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
+  constexpr int ND = DC6 ? 6 : GN_MAX_DENSE;
   __shared__ float g_mean[GN_MAX_GROUPS], g_rstd[GN_MAX_GROUPS];
   const int C = p.c1 + p.c2;
   const int n = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
@@ -202,13 +205,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   if (!active) return;
   const int p_begin = (int)((int64_t)slab * p.hw / nslab);
   const int p_end = (int)((int64_t)(slab + 1) * p.hw / nslab);
-  const int dc = DENSE ? p.dense_c : 0;
+  const int dc = DENSE ? (DC6 ? 6 : p.dense_c) : 0;
   {
     const int c0 = q * 4;
     // modulation weights as (scale, shift) PAIRS: one v_pk_fma_f32 per (channel, Pluecker component) instead of two
     // v_fma_f32; the "1 +" of (1 + scale) is folded into the pair's bias
     float a[4], b[4];
-    f32x2 wmod[4][GN_MAX_DENSE], bmod[4];
+    f32x2 wmod[4][ND], bmod[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = c0 + r, g = c / cpg;
@@ -216,9 +219,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
       b[r] = p.beta[c] - g_mean[g] * a[r];
       bmod[r] = f32x2{1.0f + (dc ? p.dense_b[c] : 0.f), dc ? p.dense_b[C + c] : 0.f};
 #pragma unroll
-      for (int j = 0; j < GN_MAX_DENSE; ++j) wmod[r][j] = f32x2{0.f, 0.f};
+      for (int j = 0; j < ND; ++j) wmod[r][j] = f32x2{0.f, 0.f};
     }
-    if (DENSE && dc == 6) {
+    if (DENSE && DC6) {
       // Pluecker modulation (6 components): the thread's 4 channels x 6 weights are 24 consecutive floats of the
       // scale half and 24 of the shift half: 2 x 6 coalesced 16-byte loads instead of 48 scalar ones
       f32x4 ws4[6], wh4[6];
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < GN_MAX_DENSE; ++j) {  // branch-free: clamped index, then select
+        for (int j = 0; j < ND; ++j) {  // branch-free: clamped index, then select
           const int c = c0 + r;
           const int jj = j < dc ? j : (dc > 0 ? dc - 1 : 0);
           const float w0 = p.dense_w[(int64_t)c * dc + jj];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
     constexpr int U = DENSE ? 3 : 2;  // pixels in flight per thread (modulated: 3 waves per SIMD need 4 to keep ~12 MB in flight)
     for (int pix0 = p_begin + pl; pix0 < p_end; pix0 += U * pl_count) {
       f32x4 v[U];
-      float dn[U][GN_MAX_DENSE];
+      float dn[U][ND];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int pix = pix0 + u * pl_count;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
         if (dc) {
           const float* dp = p.dense + ((int64_t)n * p.hw + pix) * dc;
 #pragma unroll
-          for (int j = 0; j < GN_MAX_DENSE; ++j) dn[u][j] = (j < dc) ? dp[j] : 0.f;
+          for (int j = 0; j < ND; ++j) dn[u][j] = (j < dc) ? dp[j] : 0.f;
         }
       }
 #pragma unroll
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
           if (dc) {
             f32x2 m = bmod[r];  // (1 + scale, shift)
 #pragma unroll
-            for (int j = 0; j < GN_MAX_DENSE; ++j)
+            for (int j = 0; j < ND; ++j)
               m = __builtin_elementwise_fma(wmod[r][j], f32x2{dn[u][j], dn[u][j]}, m);
             y = y * m[0] + m[1];
           }
@@ -486,7 +489,9 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
     rc = seva_check_launch("gn_finalize_kernel");
     if (rc) return rc;
   }
-  if (d->dense)
+  if (d->dense && d->dense_c == 6)
+    hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
+  else if (d->dense)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);

@@ -68,7 +68,7 @@ __device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
   int r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
   return __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // GELU with the exact (erf) definition, reference F.gelu at seva/modules/transformer.py:15.
 // erf by Abramowitz & Stegun 7.1.26: |abs error| <= 1.5e-7, branch-free, 2 transcendentals + 9 FMA-class
 // ops.  libm erff costs ~55 instructions with two divergent branches per call, which made the GEGLU
