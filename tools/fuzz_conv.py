@@ -15,16 +15,26 @@ g = torch.Generator().manual_seed(rng.randrange(1 << 30))
 def ints(shape, lo, hi):
     return torch.randint(lo, hi + 1, shape, generator=g).float().to(dev)
 bad = 0
+cnt = {'stats': 0, 'splitk': 0}
+skws = ops.splitk_workspace(42 * 33 * 31 * 4, 320, dev)
 for case in range(ncases):
-    n = rng.choice([1, 2, 3, 5])
+    n = rng.choice([1, 2, 3, 5, 42])
     ih, iw = rng.choice([4, 5, 8, 9, 16, 33]), rng.choice([4, 6, 7, 12, 16, 31])
-    cin, cout = 64 * rng.choice([1, 2, 3]), rng.choice([4, 64, 96, 160, 320])
+    cin, cout = 64 * rng.choice([1, 2, 3, 4]), rng.choice([4, 64, 96, 160, 320])
     mode = rng.choice(["s1", "s1", "s2", "up", "s2br"])
+    kn = {}
     if mode == "s2br" and (ih % 2 or iw % 2):
         mode = "s2"
-    for k, vals in (("SEVA_GEMM_BN", [None, "128", "160"]), ("SEVA_GEMM_BM", [None, "64", "128"]), ("SEVA_GEMM_CHUNKS", [None, "1", "2"])):
+    for k, vals in (("SEVA_GEMM_BN", [None, "128", "160"]), ("SEVA_GEMM_BM", [None, None, "64", "128", "160"]), ("SEVA_GEMM_CHUNKS", [None, "1", "2"])):
         v = rng.choice(vals)
+        kn[k] = v
         ops.set_knob(k[5:].lower(), -1 if v is None else int(v))  # knobs are read from the environment only at load
+    if case % 5 == 4:  # every fifth case aims at the split-K = 2 launch: small image, deep even K, no knob
+        ih, iw, cin, cout = rng.choice([4, 5, 8, 9]), rng.choice([4, 6, 7, 12]), rng.choice([128, 256]), rng.choice([160, 320])
+        mode = rng.choice(["s1", "s1", "s2"])
+        for k in kn:
+            kn[k] = None
+            ops.set_knob(k[5:].lower(), -1)
     x, w, b = ints((n, cin, ih, iw), -3, 3), ints((cout, cin, 3, 3), -2, 2), ints((cout,), -4, 4)
     xi = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
     if mode == "s2br":
@@ -35,15 +45,29 @@ for case in range(ncases):
     res = ints((n, oh * ow, cout), -9, 9) if rng.random() < 0.5 else None
     radd = ints((n, cout), -3, 3) if rng.random() < 0.5 else None
     out = torch.full((n, oh * ow, cout), float("nan"), device=dev)
-    ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w), stride=2 if mode in ("s2", "s2br") else 1,
+    stats = None
+    if cout >= 128 and rng.random() < 0.5:  # epilogue-emitted GroupNorm statistics (64-row blocks of the [n * oh * ow, cout] output)
+        stats = torch.full(ops.channel_stats_shape(n * oh * ow, cout), float("nan"), device=dev)
+    use_sk = case % 5 == 4 or rng.random() < 0.5  # split-K = 2 hand-off for the small-image launches that qualify (the others ignore the workspace)
+    cnt['stats'] += stats is not None
+    cnt['splitk'] += use_sk and mode != 'up' and oh * ow <= 128 and (9 * cin // 64) >= 16 and (9 * cin // 64) % 2 == 0 and cout >= 64 and all(os.environ.get(k) is None for k in ()) and all(v is None for v in kn.values())
+    for _ in range(2):
+      ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w), stride=2 if mode in ("s2", "s2br") else 1,
                 upsample=mode == "up", pad_br_only=mode == "s2br", bias=b, residual=res, row_add=radd,
-                rows_per_group=oh * ow if radd is not None else 0, out_f32=out)
+                rows_per_group=oh * ow if radd is not None else 0, out_f32=out, ch_stats=stats, splitk_ws=skws if use_sk else None)
     refl = ref.permute(0, 2, 3, 1).reshape(n, oh * ow, cout)
     if radd is not None: refl = refl + radd[:, None, :]
     if res is not None: refl = refl + res
     torch.cuda.synchronize()
-    if not torch.equal(out, refl):
+    ok = torch.equal(out, refl)
+    if stats is not None:  # sums of small integers are exact in fp32 whatever the order; the sums of squares can pass 2^24
+        M = n * oh * ow
+        nb = stats.shape[0]
+        rp = torch.zeros(nb * 64, cout, device=dev); rp[:M] = refl.reshape(M, cout)
+        rp = rp.view(nb, 64, cout)
+        ok = ok and torch.equal(stats[:, 0], rp.sum(1)) and torch.allclose(stats[:, 1].double(), (rp.double() ** 2).sum(1), rtol=1e-5, atol=0)
+    if not ok:
         bad += 1
-        print("MISMATCH", case, n, ih, iw, cin, cout, mode, {k: os.environ.get(k) for k in ("SEVA_GEMM_BN", "SEVA_GEMM_BM", "SEVA_GEMM_CHUNKS")}, flush=True)
-print(f"conv fuzz: {ncases} cases, {bad} mismatches")
+        print("MISMATCH", case, n, ih, iw, cin, cout, mode, stats is not None, use_sk, {k: os.environ.get(k) for k in ("SEVA_GEMM_BN", "SEVA_GEMM_BM", "SEVA_GEMM_CHUNKS")}, flush=True)
+print(f"conv fuzz: {ncases} cases, {bad} mismatches; with statistics {cnt['stats']}, split-K candidates {cnt['splitk']}")
 sys.exit(1 if bad else 0)
