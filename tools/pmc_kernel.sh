@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over one kernel of a small driver script (one counter group per pass; kernel-trace only, never combined with
-# runtime traces).   usage: tools/pmc_kernel.sh <driver.py> <kernel-name substring> <tag>   -> gpurun_out/pmc_<tag>/summary.txt
+# runtime traces).   usage: tools/pmc_kernel.sh <driver.py> <kernel-name substring[|substring...]> <tag>   -> gpurun_out/pmc_<tag>/summary.txt
 set -e
 drv=$1; pat=$2; tag=$3
 out=$PWD/gpurun_out/pmc_$tag
@@ -17,17 +17,21 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_MFMA
 done
 PAT="$pat" OUT="$out" python3 - <<'PY'
 import csv, glob, collections, os
-out, pat = os.environ["OUT"], os.environ["PAT"]
-tot = collections.defaultdict(list)
+out = os.environ["OUT"]
+pats = os.environ["PAT"].split("|")  # several kernels of one driver: "patA|patB" -> one block per pattern
+rows = []
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if pat in r["Kernel_Name"]:
-            tot[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows += list(csv.DictReader(open(f)))
 with open(out + "/summary.txt", "w") as fo:
-    fo.write(f"kernel pattern: {pat}\n")
-    for k in sorted(tot):
-        v = tot[k]
-        line = f"{k:28s} launches {len(v)}  mean {sum(v)/len(v):.4g}"
-        print(line); fo.write(line + "\n")
+    for pat in pats:
+        tot = collections.defaultdict(list)
+        for r in rows:
+            if pat in r["Kernel_Name"]:
+                tot[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        fo.write(f"kernel pattern: {pat}\n"); print("kernel pattern:", pat)
+        for k in sorted(tot):
+            v = tot[k]
+            line = f"{k:28s} launches {len(v)}  mean {sum(v)/len(v):.4g}"
+            print(line); fo.write(line + "\n")
 PY
 find $out -name "*counter_collection.csv" -delete
