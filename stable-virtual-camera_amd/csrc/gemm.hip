@@ -77,12 +77,19 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false, bool SPLITK = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+// NW: waves per workgroup.  4 (2 x 2 wave tiles, two workgroups per CU) everywhere in production; the experimental library also
+// instantiates 8 (2 x 4 wave tiles, ONE workgroup per CU): two N-sibling 128 x 160 tiles fused so that their A rows are staged once
+// (128 x 320: 0.0109 operand bytes per FLOP; same per-wave tile, registers and waves per SIMD as 128 x 160) -- measured slower.
+template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false, bool SPLITK = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   const int dbg = DBGK ? p.dbg : 0;
-  constexpr int WM = ASTAT ? BM / 4 : BM / 2, WN = ASTAT ? BN : BN / 2;  // per-wave tile
+  static_assert(NW == 4 || (NW == 8 && !DBGK && !PAIRED && !ASTAT && !FP8 && !SPLITK), "8 waves: plain fp32-output kernels only");
+  constexpr int WNW = NW / 2;  // waves along N
+  constexpr int WM = ASTAT ? BM / 4 : BM / 2, WN = ASTAT ? BN : BN / WNW;  // per-wave tile
   constexpr int MI = WM / 16, NJ = WN / 16;
-  constexpr int A_PASSES = ASTAT ? 0 : BM / 32, B_PASSES = BN / 32;  // 8-row wave-instructions per wave
+  constexpr int A_PASSES = ASTAT ? 0 : BM / (8 * NW), B_PASSES = BN / (8 * NW);  // 8-row wave-instructions per wave
+  static_assert(ASTAT || BM % (8 * NW) == 0, "A rows must split evenly over the waves");
+  static_assert(BN % (8 * NW) == 0, "B rows must split evenly over the waves");
   constexpr int A_BYTES = ASTAT ? 0 : BM * 128, B_BYTES = BN * 128;
   constexpr int KS_A = 10;  // ASTAT: k-steps of 32 held in registers (K <= 320)
   static_assert(!ASTAT || (PAIRED && MODE == 0 && !DBGK), "ASTAT rides on the ASYNC f16-only schedule");
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = ASTAT ? wave : wave >> 1, wn = ASTAT ? 0 : wave & 1;
+  const int wm = ASTAT ? wave : wave / WNW, wn = ASTAT ? 0 : wave % WNW;
 
   // Experiment knob (SEVA_GEMM_STAGGER): pseudo-random start delay to de-phase the workgroups'
   // main loops and epilogues.  Measured: no gain at any quantum, so it lives in the ablation build only.
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   int a_q[AP];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
-    const int row = wave * (BM / 4) + 8 * i + sr;  // row inside the tile
+    const int row = wave * (BM / NW) + 8 * i + sr;  // row inside the tile
     const int q = sp ^ ((row >> 1) & 7);           // logical 16-B chunk this lane fetches
     a_q[i] = q;
     a_mask[i] = 0;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   auto set_b_tile = [&](int tn) {
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      const int row = wave * (BN / 4) + 8 * i + sr;
+      const int row = wave * (BN / NW) + 8 * i + sr;
       const int q = sp ^ b_key(row);
       int64_t n = (int64_t)tn * BN + row;
       if (n >= p.N) n = p.N - 1;
@@ -218,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   int st_ky = 0, st_kx = 0, st_ci0 = 0;  // MODE 1: tap / channel position of the next K-tile to stage
   auto stage = [&](int buf, int kt) {
-    char* const la = lds_a + buf * A_BYTES + wave * (BM / 4) * 128;
-    char* const lb = lds_b + buf * B_BYTES + wave * (BN / 4) * 128;
+    char* const la = lds_a + buf * A_BYTES + wave * (BM / NW) * 128;
+    char* const lb = lds_b + buf * B_BYTES + wave * (BN / NW) * 128;
     if (MODE == 0) {
       if (!(dbg & 128)) {  // ablation bit 128: no A-operand staging (bound for an A-stationary kernel)
 #pragma unroll
@@ -298,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     glds16_raw(p.w_exp + f, wexp_slot_u32);
   };
   auto stage_async = [&](int buf, int kt) {
-    const unsigned la = lds_base_u32 + buf * A_BYTES + wave * (BM / 4) * 128;
-    const unsigned lb = lds_base_u32 + 2 * A_BYTES + buf * B_BYTES + wave * (BN / 4) * 128;
+    const unsigned la = lds_base_u32 + buf * A_BYTES + wave * (BM / NW) * 128;
+    const unsigned lb = lds_base_u32 + 2 * A_BYTES + buf * B_BYTES + wave * (BN / NW) * 128;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) glds16_raw(a_ptr[i] + (int64_t)kt * BK, la + i * 1024);
 #pragma unroll
@@ -798,11 +805,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false, bool FP8 = false, bool SPLITK = false>
+template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false, bool FP8 = false, bool SPLITK = false, int NW = 4>
 int launch_p(const GemmArgs& a, hipStream_t s) {
   // + bias slots (ASYNC) + weight-scale slots (FP8 ASYNC)
   constexpr int lds = 2 * ((ASTAT ? 0 : BM) + BN) * 128 + (ASTAT ? 8192 : PAIRED ? 4096 : 0) + (FP8 && PAIRED ? 4096 : 0);
-  constexpr bool DBG_BUILD = !ASTAT && !FP8 && !SPLITK;  // the ablation instantiation only exists for the staged-A f16 kernels
+  constexpr bool DBG_BUILD = !ASTAT && !FP8 && !SPLITK && NW == 4;  // the ablation instantiation only exists for the staged-A f16 kernels
   // the dynamic-LDS attribute is per device: one bit per device ordinal and instantiation (a second GPU in the
   // same process would otherwise launch 72-80 KB kernels without it)
   static std::atomic<uint64_t> attr_devs{0};
@@ -810,7 +817,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK, NW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (DBG_BUILD)
       (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED, false>,
@@ -863,7 +870,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
       return seva_check_launch("gemm_kernel");
     }
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK>), dim3((unsigned)nb), dim3(256), lds, s, args);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK, NW>), dim3((unsigned)nb), dim3(64 * NW), lds, s, args);
   return seva_check_launch("gemm_kernel");
 }
 
@@ -1066,6 +1073,15 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   {
     const bool dbg_run = g_seva_knobs.gemm_dbg >= 0 || g_seva_knobs.gemm_stagger >= 0;
     const bool f16_only = d->mode == 0 && d->out_f16 && !d->out_f32 && !d->residual;
+#ifdef SEVA_EXPERIMENTAL
+    // 8-wave 128 x 320 tiles (knob gemm_bn = 320; experimental library only): one workgroup per CU whose two halves share the
+    // staged A rows.  Bitwise equal (statistics included) and 13-23 % fewer operand bytes per FLOP -- and 15-30 % SLOWER on the
+    // GEMMs, level on the convs (tools/ktile320.py, profiles/r02_ktile320.log): one 8-wave barrier domain per CU loses more than
+    // the shared A rows return.
+    if (g_seva_knobs.gemm_bn == 320 && d->N % 320 == 0 && !dbg_run && !d->upsample && !a.sk_ws && !f16_only && d->out_f32)
+      return d->mode == 0 ? launch_p<128, 320, 0, 0, false, false, false, false, 8>(a, s)
+                          : launch_p<128, 320, 1, 0, false, false, false, false, 8>(a, s);
+#endif
     const bool big = g_seva_knobs.gemm_bm == 160 ||
                      (g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0 && !dbg_run && !half_m && d->M >= 2048);
     if (big && wide && !narrow && !d->ch_stats && !d->upsample && !a.sk_ws && !f16_only)
