@@ -87,10 +87,16 @@ def _windows(pass_id, base, T, chunks, src_pool, tgt_pool, padding_mode="last"):
 
 
 def plan_trajectory(c2ws: torch.Tensor, input_ids: Sequence[int], T: int = 21, chunk_strategy: str = "interp",
-                    first_pass_strategy: str = "gt", options: dict | None = None,
-                    task: str = "img2trajvid") -> TrajectoryPlan:
+                    first_pass_strategy: str = "gt-nearest", options: dict | None = None,
+                    task: str = "img2trajvid", refine_anchors: bool = True) -> TrajectoryPlan:
     """Anchors + windows of both passes for one trajectory; frame ids index `c2ws` (inputs first, like the reference's
-    `input_indices` convention in run_one_scene)."""
+    `input_indices` convention in run_one_scene).
+
+    Defaults are the reference's (eval.py:1656 `chunk_strategy_first_pass` = "gt-nearest"; eval.py:1459 + 1869-1885: the
+    second pass targets EVERY non-input frame, so the anchors -- which the `interp` chunker places as the first target of
+    the range they open -- are generated again in pass 2 and the trajectory's anchor frames are second-pass samples;
+    golden: tests/golden/g10_two_pass_plans.json).  `refine_anchors=False` is this package's cheaper variant: the second
+    pass skips the anchors and their final latents are the first-pass samples (one target slot more per range)."""
     n = c2ws.shape[0]
     ins = [int(i) for i in input_ids]
     opts = {"sampler_verbose": False, **(options or {}), "chunk_strategy": chunk_strategy}
@@ -111,7 +117,8 @@ def plan_trajectory(c2ws: torch.Tensor, input_ids: Sequence[int], T: int = 21, c
     w1 = _windows(1, 0, T, p1, pool1, anchors, opts.get("t_padding_mode", "last"))
     order = np.argsort(ins + anchors).tolist()
     pool2 = [(ins + anchors)[o] for o in order]
-    rest = [i for i in range(n) if i not in set(ins) and i not in set(anchors)]
+    skip = set(ins) if refine_anchors else set(ins) | set(anchors)
+    rest = [i for i in range(n) if i not in skip]
     p2 = planner.chunk_input_and_test(T, c2ws[pool2], c2ws[rest], [float(i) for i in pool2], [float(r) for r in rest],
                                       opts, task=task, chunk_strategy=chunk_strategy,
                                       gt_input_inds=[order.index(i) for i in range(len(ins))])
@@ -169,7 +176,8 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
                    input_ids: Sequence[int], *, clip_token: torch.Tensor | None = None, clip_fn: Callable | None = None,
                    T: int = 21, num_steps: int = 50, cfg: float = 2.0, cfg_min: float = 1.2, guider: int = 1,
                    camera_scale: float = 2.0, seed: int = 23, chunk_strategy: str = "interp",
-                   first_pass_strategy: str = "gt", device=None, group=None, ae=None, handoff: str = "latent",
+                   first_pass_strategy: str = "gt-nearest", refine_anchors: bool = True, device=None, group=None, ae=None,
+                   handoff: str = "latent",
                    plan: TrajectoryPlan | None = None, timers: dict | None = None,
                    sampler_hook: Callable | None = None, conditioner: Callable | None = None,
                    input_rgb: torch.Tensor | None = None) -> dict:
@@ -180,7 +188,7 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
     rank, world = _rank_world(group)
     device = torch.device(device) if device is not None else input_latents.device
     h, w = input_latents.shape[-2:]
-    plan = plan or plan_trajectory(c2ws, input_ids, T, chunk_strategy, first_pass_strategy)
+    plan = plan or plan_trajectory(c2ws, input_ids, T, chunk_strategy, first_pass_strategy, refine_anchors=refine_anchors)
     rgb_of: dict = {}
     if conditioner is not None:
         # the reference's rule (eval.py:1248): token of a window = mean CLIP embedding of its conditioning views' RGB
@@ -289,7 +297,7 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
     n = c2ws.shape[0]
     final = torch.zeros((n, 4, h, w), device=device)
     filled = torch.zeros(n, dtype=torch.bool)
-    for fid in plan.input_ids + plan.anchor_ids:
+    for fid in plan.input_ids + plan.anchor_ids:  # (anchors: first-pass samples, overwritten below when pass 2 regenerates them)
         final[fid] = latents_of[fid]
         filled[fid] = True
     for i, win in enumerate(plan.pass2):

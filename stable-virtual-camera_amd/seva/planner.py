@@ -345,10 +345,14 @@ def chunk_input_and_test(T, input_c2ws, test_c2ws, input_ords, test_ords, option
 
 # ---------------------------------------------------------------------------------------------------------------
 def two_pass_plan(num_frames_total: int, input_indices: Sequence[int], c2ws, T: int = 21,
-                  chunk_strategy: str = "interp", options: dict | None = None, task: str = "img2trajvid"):
+                  chunk_strategy: str = "interp", options: dict | None = None, task: str = "img2trajvid",
+                  first_pass_strategy: str = "gt-nearest", refine_anchors: bool = True):
     """Convenience for the multi-GPU driver: anchors, first-pass windows (serial) and second-pass windows
     (independent units) of one trajectory, composed from the functions above the way `run_one_scene` does
-    (reference eval.py:1700-1910).  `c2ws`: (num_frames_total, 4, 4); `input_indices` must come first in order."""
+    (reference eval.py:1653-1885: first pass `chunk_strategy_first_pass` = "gt-nearest" by default; the second pass
+    conditions on the argsorted [inputs + anchors] and targets EVERY non-input frame, anchors included).
+    `refine_anchors=False`: second pass without the anchors (this package's cheaper variant).
+    `c2ws`: (num_frames_total, 4, 4); `input_indices` must come first in order."""
     opts = {"sampler_verbose": False, **(options or {}), "chunk_strategy": chunk_strategy}
     vd = {"T": T, "options": opts}
     n_in = len(input_indices)
@@ -357,9 +361,11 @@ def two_pass_plan(num_frames_total: int, input_indices: Sequence[int], c2ws, T: 
     anchors = [int(v) for v in infer_prior_inds(c2ws, n_prior, list(input_indices), opts)]
     ins = list(input_indices)
     pass1 = chunk_input_and_test(T1, c2ws[ins], c2ws[anchors], [float(i) for i in ins], [float(a) for a in anchors],
-                                 opts, task=task, chunk_strategy="gt", gt_input_inds=list(range(n_in)))
-    rest = [i for i in range(num_frames_total) if i not in ins and i not in anchors]
-    pass2 = chunk_input_and_test(T2, c2ws[ins + anchors], c2ws[rest], [float(i) for i in ins + anchors],
+                                 opts, task=task, chunk_strategy=first_pass_strategy, gt_input_inds=list(range(n_in)))
+    order = np.argsort(ins + anchors).tolist()
+    pool = [(ins + anchors)[o] for o in order]
+    rest = [i for i in range(num_frames_total) if i not in ins and (refine_anchors or i not in anchors)]
+    pass2 = chunk_input_and_test(T2, c2ws[pool], c2ws[rest], [float(i) for i in pool],
                                  [float(r) for r in rest], opts, task=task, chunk_strategy=chunk_strategy,
-                                 gt_input_inds=list(range(n_in)))
+                                 gt_input_inds=[order.index(i) for i in range(n_in)])
     return {"anchors": anchors, "pass1": pass1, "pass2": pass2, "T": [T1, T2]}

@@ -51,17 +51,24 @@ def _run(group=None, **kw):
                                    device="cpu", group=group, **kw)
 
 
-def test_plan_covers_the_168_view_orbit():
+@pytest.mark.parametrize("refine", [True, False])
+def test_plan_covers_the_168_view_orbit(refine):
     """1 input + 167 targets, T=21, `interp`: 20 anchors, 1 first-pass window, 10 second-pass windows whose neighbours share
-    their boundary anchor (reference planner facts), every frame generated exactly once."""
+    their boundary anchor (reference planner facts).  Default (the reference's composition): the second pass
+    generates every non-input frame, anchors included; `refine_anchors=False`: every frame generated exactly once."""
     from seva import pipeline
     c2ws, _, _, _ = _scene()
-    plan = pipeline.plan_trajectory(c2ws, [0], T=21)
+    plan = pipeline.plan_trajectory(c2ws, [0], T=21, refine_anchors=refine)
     assert len(plan.anchor_ids) == 20 and len(plan.pass1) == 1 and len(plan.pass2) == 10
     assert plan.anchor_ids == sorted(set(plan.anchor_ids)) and plan.anchor_ids[-1] == 167 and 0 not in plan.anchor_ids
-    assert not plan.pass1_serial
-    gen = [f for w in plan.pass1 + plan.pass2 for f in w.target_ids]
-    assert sorted(gen) == list(range(1, 168))
+    assert plan.pass1_serial  # the reference's default first-pass strategy, "gt-nearest", chains its windows
+    assert not pipeline.plan_trajectory(c2ws, [0], T=21, first_pass_strategy="gt").pass1_serial
+    gen2 = [f for w in plan.pass2 for f in w.target_ids]
+    if refine:
+        assert sorted(gen2) == list(range(1, 168))
+    else:
+        assert sorted(gen2 + plan.anchor_ids) == list(range(1, 168))
+    assert sorted(f for w in plan.pass1 for f in w.target_ids) == plan.anchor_ids
     for a, b in zip(plan.pass2[:-1], plan.pass2[1:]):
         assert a.source_ids[-1] == b.source_ids[0]  # the shared "overlap" anchor
     for w in plan.pass1 + plan.pass2:
@@ -76,10 +83,15 @@ def test_single_process_trajectory_is_deterministic_and_window_order_independent
     b = _run()
     assert torch.equal(a["latents"], b["latents"]) and torch.isfinite(a["latents"]).all()
     assert a["latents"].shape == (168, 4, 8, 8)
-    # input frame untouched, anchors = pass-1 output
+    # input frame untouched; anchors = second-pass samples by default (reference), first-pass samples with refine_anchors=False
     _, _, lat, _ = _scene()
     assert torch.equal(a["latents"][0], lat[0])
     assert float(a["latents"][1:].abs().mean()) > 0
+    c = _run(refine_anchors=False)
+    anchors = a["plan"].anchor_ids
+    others = [f for f in range(1, 168) if f not in anchors]
+    assert not torch.equal(a["latents"][anchors], c["latents"][anchors])
+    assert torch.isfinite(c["latents"]).all() and c["latents"][others].abs().mean() > 0
 
 
 def _free_port():
@@ -155,5 +167,9 @@ def test_reference_style_rgb_handoff_and_per_window_clip_token(monkeypatch):
     assert seen == [len(w.source_ids) for w in plan.pass1 + plan.pass2]
     # anchors went through the RGB round trip: what pass 2 conditioned on is encode(decode(.)), whose 4th channel is the
     # mean of the first three divided by 1.5 under this stand-in
-    a = plan.anchor_ids[0]
+    # (visible in the final latents only when the second pass does not regenerate the anchors)
+    seen.clear()
+    res = pipeline.run_trajectory(_fake_net, lat, c2ws, Ks, [0], T=21, num_steps=2, seed=5, device="cpu", ae=FakeAE(),
+                                  handoff="rgb", conditioner=fake_clip, input_rgb=rgb_in, refine_anchors=False)
+    a = res["plan"].anchor_ids[0]
     assert torch.allclose(res["latents"][a][3], res["latents"][a][:3].mean(0) / 1.5, atol=1e-6)

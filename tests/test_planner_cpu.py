@@ -89,8 +89,9 @@ def test_chunk_error_behaviour(cams):
 def test_two_pass_plan_of_168_views(cases, cams):
     """1 input + 167 targets, T=21, interp -> 20 anchors, 1 serial first-pass window, 10 independent
     second-pass windows whose neighbours share their boundary anchor."""
-    g = cases["plan168"]
-    plan = P.two_pass_plan(168, [0], cams["plan168"], T=21, chunk_strategy="interp")
+    g = cases["plan168"]  # (this golden: first pass "gt", second pass without the anchors = refine_anchors=False)
+    plan = P.two_pass_plan(168, [0], cams["plan168"], T=21, chunk_strategy="interp", first_pass_strategy="gt",
+                           refine_anchors=False)
     assert plan["anchors"] == g["prior_inds"] and len(plan["anchors"]) == g["num_prior_frames"] == 20
     assert plan["pass1"][0] == g["pass1_chunks"] and len(plan["pass1"][0]) == 1
     assert plan["pass2"][0] == g["pass2_chunks"] and len(plan["pass2"][0]) == 10
@@ -101,3 +102,38 @@ def test_two_pass_plan_of_168_views(cases, cams):
     from seva.distributed import shard_windows
     shards = [shard_windows(len(wins), r, 8) for r in range(8)]
     assert sorted(i for s in shards for i in s) == list(range(10)) and max(len(s) for s in shards) == 2
+
+
+def test_two_pass_plan_is_the_references_run_one_scene_composition():
+    """Default `two_pass_plan` / `pipeline.plan_trajectory` == what the reference's run_one_scene composes in its 2-pass branch
+    (eval.py:1653-1885): first pass "gt-nearest", second pass over the argsorted [inputs + anchors] pool with EVERY
+    non-input frame as a target (the anchors are generated again).  Golden: window lists produced by the reference's own
+    functions in that composition (tests/golden/g10_two_pass_plans.json, oracle/make_goldens_next.py:g10_two_pass)."""
+    from seva import pipeline
+    with open(os.path.join(GOLD, "g10_two_pass_plans.json")) as f:
+        gold = json.load(f)
+    z = np.load(os.path.join(GOLD, "g10_two_pass_cams.npz"))
+    assert set(gold) >= {"orbit168", "orbit168_gt", "two_in80", "three60", "orbit300", "orbit100_nearest"}
+    for name, g in gold.items():
+        c2ws = torch.from_numpy(z[name])
+        ins, n = g["input_ids"], g["n"]
+        plan = P.two_pass_plan(n, ins, c2ws, T=g["T"], chunk_strategy=g["chunk_strategy"],
+                               first_pass_strategy=g["first_pass_strategy"])
+        assert plan["anchors"] == g["prior_inds"], name
+        for k, (ours, ref) in {"pass1": (plan["pass1"], g["pass1"]), "pass2": (plan["pass2"], g["pass2"])}.items():
+            assert list(ours[0]) == ref["chunks"], (name, k)
+            assert [list(ours[1]), list(ours[2]), list(ours[3]), list(ours[4])] == \
+                   [ref["input_inds"], ref["input_sels"], ref["test_inds"], ref["test_sels"]], (name, k)
+        # the driver's typed plan: same windows, in trajectory frame ids
+        tp = pipeline.plan_trajectory(c2ws, ins, T=g["T"], chunk_strategy=g["chunk_strategy"],
+                                      first_pass_strategy=g["first_pass_strategy"])
+        assert tp.anchor_ids == g["prior_inds"] and tp.pass1_serial == (g["first_pass_strategy"] != "gt")
+        order = np.argsort(ins + g["prior_inds"]).tolist()
+        pool = [(ins + g["prior_inds"])[o] for o in order]
+        test = [i for i in range(n) if i not in ins]
+        assert len(tp.pass2) == len(g["pass2"]["chunks"])
+        for w, ii, ti, ts in zip(tp.pass2, g["pass2"]["input_inds"], g["pass2"]["test_inds"], g["pass2"]["test_sels"]):
+            assert w.source_ids == [pool[j] for j in ii] and w.target_ids == [test[j] for j in ti] and w.target_slots == list(ts)
+        # every non-input frame is a second-pass target exactly once; every anchor is among them
+        tg = [f for w in tp.pass2 for f in w.target_ids]
+        assert sorted(tg) == test and set(g["prior_inds"]) <= set(tg)
