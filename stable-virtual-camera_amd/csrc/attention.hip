@@ -680,6 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   }
 }
 
+#ifdef SEVA_EXPERIMENTAL  // experimental library only (make exp; knob attn_two = 3): measured +1 %, not shipped in libseva_hip.so
 // ---------------------------------------------------------------------------------------------
 // Software-pipelined kernel (engine path: pre-scaled q, tr-reads, lq > 32).  Same operand layouts, LDS tile images,
 // online-softmax arithmetic and rounding as attn_kernel<4, 64, true, false, true>; what changes is WHEN things issue.
@@ -1019,6 +1020,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
     if (q0 + row < p.lq) *(uint4*)(obase + (int64_t)(q0 + row) * p.o_sl + lchunk * 8) = v;
   }
 }
+#endif  // SEVA_EXPERIMENTAL
 
 template <int NW, int KT>
 int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr, bool pre) {
@@ -1074,7 +1076,7 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr, pre);
   // Two-query-block kernel (64 queries per wave, K / V fragments shared by both blocks): the default for long sequences
   // (+3.6 ... +6.2 % at the three long shapes of a step, -1 % at L = 1296).  Knob attn_two: 0 forces attn_kernel, 1 selects this
-  // kernel from lq >= 512, 3 the software-pipelined kernel above.
+  // kernel from lq >= 512, 3 the software-pipelined kernel above (experimental library only).
   const int two = g_seva_knobs.attn_two;
   if (pre && use_tr && !a.dbg && ((two < 0 && d->lq >= 2048) || ((two == 1 || two == 2) && d->lq >= 512))) {
     AttnArgs args = a;
@@ -1087,5 +1089,18 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
     hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
     return seva_check_launch("attn2_kernel");
   }
+#ifdef SEVA_EXPERIMENTAL
+  if (pre && use_tr && !a.dbg && two == 3 && d->lq >= 512) {  // software-pipelined kernel (experimental library only)
+    AttnArgs args = a;
+    args.qblocks = (a.lq + 127) / 128;
+    const int64_t nb = batch * a.heads * args.qblocks;
+    if (nb <= 0 || nb > 0x7fffffff) {
+      seva_set_error("attention: bad grid %lld", (long long)nb);
+      return SEVA_ERR_ARG;
+    }
+    hipLaunchKernelGGL((attn3_kernel<64, 4>), dim3((unsigned)nb), dim3(256), 0, s, args);
+    return seva_check_launch("attn3_kernel");
+  }
+#endif
   return launch<4, 64>(a, batch, s, use_tr, pre);
 }

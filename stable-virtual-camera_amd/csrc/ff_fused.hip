@@ -50,6 +50,7 @@ __device__ __forceinline__ void ff_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef SEVA_EXPERIMENTAL  // 4-wave variant: experimental library only (knob ff_variant = 4); the 8-wave kernel below is the product
 template <int C>
 __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FfArgs p) {
   static_assert(C % 64 == 0 && C <= 320, "C must be a multiple of 64, at most 320");
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FfArgs p) {
     }
   }
 }
+#endif  // SEVA_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------------------------------------------
 // 8-wave variant: the same 128-row tile, but TWO waves per 32-row group (2 waves per SIMD -> one wave's LDS / barrier waits
@@ -518,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
   }
 }
 
+#ifdef SEVA_EXPERIMENTAL
 template <int C>
 int ff_launch(const FfArgs& a, hipStream_t s) {
   constexpr int lds = 2 * 128 * 128 + 2 * C * 128 + 8 * C * 4;
@@ -532,6 +535,7 @@ int ff_launch(const FfArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((ff_fused_kernel<C>), dim3((unsigned)a.tiles_m), dim3(256), lds, s, a);
   return seva_check_launch("ff_fused_kernel");
 }
+#endif
 
 template <int C>
 int ff_launch8(const FfArgs& a, hipStream_t s) {
@@ -579,6 +583,7 @@ extern "C" int seva_ff_fused_f16(const seva_ff_desc* d, seva_stream_t stream) {
   const double bytes = (double)d->M * C * ((d->ln_x ? 4.0 : 2.0) + (d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) + (d->out_f16 ? 2.0 : 0.0)) +
                        2.0 * (8.0 * C * C + 4.0 * C * C);
   SevaProfScope prof(0, flops, s, bytes);
+#ifdef SEVA_EXPERIMENTAL
   if (g_seva_knobs.ff_variant == 4 && !d->ln_x) {  // knob ff_variant = 4: the 4-wave kernel (benchmarking); default: 8 waves
     switch (d->C) {
       case 64: return ff_launch<64>(a, s);
@@ -587,6 +592,7 @@ extern "C" int seva_ff_fused_f16(const seva_ff_desc* d, seva_stream_t stream) {
       default: return ff_launch<320>(a, s);
     }
   }
+#endif
   switch (d->C) {
     case 64: return ff_launch8<64>(a, s);
     case 128: return ff_launch8<128>(a, s);

@@ -1047,6 +1047,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   // 5-25 % slower: profiles/r01_kbench_bn64.log.)  SEVA_GEMM_BN=128|160 forces the width (benchmark knob).
   bool wide = d->N % 160 == 0;
   if (g_seva_knobs.gemm_bn > 0) wide = g_seva_knobs.gemm_bn == 160;
+#ifdef SEVA_EXPERIMENTAL  // stream-K lives in the experimental library only (knob gemm_streamk = 1): slower on every shape
   // Stream-K (gemm_sk.hip) for fp32-output launches whose 128-row tile count leaves the last round of the 512 workgroup slots
   // partly empty (18 x 18 level: 856 tiles = 1.67 rounds).  Bitwise equal to the unsplit kernel -- and SLOWER on every shape of
   // this network (-1 ... -23 %, tools/kstreamk.py): equal K-ranges desynchronise the sibling tiles that otherwise stream one A
@@ -1065,6 +1066,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
       return seva_gemm_streamk_launch(a, d->mode, bn, P, s);
     }
   }
+#endif  // SEVA_EXPERIMENTAL
   // 160 x 160 tiles for the fp32-output kernels (not the f16-only ASYNC ones: their bias slots would not fit): 0.0125 operand bytes
   // per FLOP instead of 0.0141, 50 instead of 40 MFMAs per wave and barrier; two workgroups take EXACTLY the CU's 160 KiB of LDS
   // and all 256 registers (no spill in GEMM mode, 7 dwords in conv mode).  Bitwise the same outputs; -3 ... -10 % on every shape

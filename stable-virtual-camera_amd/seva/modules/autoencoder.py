@@ -205,19 +205,33 @@ class AutoEncoder(nn.Module):
     def _encode(self, x: torch.Tensor) -> torch.Tensor:
         return self.encoder_engine().encode(x, self.scale_factor)
 
-    def _frames_per_pass(self, chunk_size: int | None) -> int | None:
+    ARENA_BYTES_PER_PIXEL = 4.0e9 / (576 * 576)  # decoder arena per frame, measured at 576 x 576 (profiles/r02_kvae.log)
+
+    def _frames_per_pass(self, chunk_size: int | None, pixels: int = 576 * 576, device=None) -> int | None:
         """`chunk_size` is the reference's memory knob (demo.py: AutoEncoder(chunk_size=1), decoding_t=1: 21 sequential
         single-frame passes per window).  Every kernel of the VAE engines is sample-independent and bitwise batch-invariant
         (GroupNorm slab counts depend on the image only; tested), so the frames-per-pass actually executed is a pure
-        performance choice: at 576x576 one decode pass costs 9.5 ms for 1 frame but 5.6 ms/frame for 7 (4 GB of arena per
-        frame; profiles/r02_kvae.log).  SEVA_VAE_FRAMES_PER_PASS (default 7) raises it; results are identical bit for bit."""
+        performance choice: at 576x576 one decode pass costs 9.5 ms for 1 frame but 5.6 ms/frame for 7 -- at about 4 GB of
+        arena PER FRAME.  The caller's chunk_size is therefore raised (results identical bit for bit) only
+          * to SEVA_VAE_FRAMES_PER_PASS when the user sets it, or
+          * up to 7 frames while the arena of that many frames fits in HALF of the card's currently free memory
+            (the UNet and CLIP engines share the card; an explicit chunk_size=1 on a nearly full card stays 1)."""
         chunk_size = chunk_size or self.chunk_size
         if chunk_size is None:
             return None
-        return max(int(chunk_size), int(os.environ.get("SEVA_VAE_FRAMES_PER_PASS", "7")))
+        env = os.environ.get("SEVA_VAE_FRAMES_PER_PASS")
+        if env is not None:
+            return max(int(chunk_size), int(env))
+        want = 7
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+            fit = int(0.5 * free / (self.ARENA_BYTES_PER_PIXEL * max(int(pixels), 1)))
+        except Exception:  # no device query available: honour the caller's value
+            fit = 0
+        return max(int(chunk_size), min(want, fit))
 
     def encode(self, x: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
-        chunk_size = self._frames_per_pass(chunk_size)
+        chunk_size = self._frames_per_pass(chunk_size, x.shape[-2] * x.shape[-1], x.device)
         if chunk_size is not None:
             return torch.cat([self._encode(xc) for xc in x.split(chunk_size)], dim=0)
         return self._encode(x)
@@ -226,7 +240,7 @@ class AutoEncoder(nn.Module):
         return self.engine().decode(z, self.scale_factor)
 
     def decode(self, z: torch.Tensor, chunk_size: int | None = None) -> torch.Tensor:
-        chunk_size = self._frames_per_pass(chunk_size)
+        chunk_size = self._frames_per_pass(chunk_size, 64 * z.shape[-2] * z.shape[-1], z.device)
         if chunk_size is not None:
             return torch.cat([self._decode(zc) for zc in z.split(chunk_size)], dim=0)
         return self._decode(z)

@@ -70,6 +70,7 @@ def gemm(
     if splitk_ws is not None and not fp8:
         assert splitk_ws.dtype == F32 and splitk_ws.is_contiguous()
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * 4
+        _register_handoff_ws(splitk_ws)
     if fp8:
         assert w_exp.dtype == U8 and w_exp.numel() == N and (out_f8 is None or out_f8.dtype == U8)
         d.w_exp, d.out_f8 = w_exp.data_ptr(), ptr(out_f8)
@@ -86,6 +87,43 @@ STATS_ROWS = 64  # rows per block of the epilogue-emitted GroupNorm statistics (
 def channel_stats_shape(rows: int, channels: int) -> tuple[int, int, int]:
     """Shape of the f32 buffer a GEMM / conv fills through `ch_stats`: [row blocks][sum | sum of squares][channel]."""
     return ((rows + STATS_ROWS - 1) // STATS_ROWS, 2, channels)
+
+
+# Split-K hand-off workspaces that launches have used (data_ptr -> weak reference).  The consumer workgroup of a split tile
+# waits for its producer with a BOUNDED spin (csrc/gemm.hip); a give-up leaves a wrong tile and counts itself in int slot
+# SPLITK_ERROR_SLOT of the workspace.  `check_handoffs` makes that loud: it is called where a host sync exists anyway (end of a
+# sampler trajectory, `prof_collect`, the GPU tests), never inside the step loop.
+SPLITK_FLAGS = 16384
+SPLITK_ERROR_SLOT = 16383
+_handoff_ws: dict = {}
+
+
+def _register_handoff_ws(ws: torch.Tensor) -> None:
+    if ws.data_ptr() not in _handoff_ws:
+        import weakref
+
+        _handoff_ws[ws.data_ptr()] = weakref.ref(ws)
+
+
+def check_handoffs() -> None:
+    """Raise SevaNativeError if any split-K consumer gave up waiting for its producer since the last check (the affected
+    outputs are wrong).  On error the flag area is zeroed so that a stale flag cannot corrupt the next launch.  Host-syncs."""
+    bad = []
+    for key, ref in list(_handoff_ws.items()):
+        ws = ref()
+        if ws is None or ws.data_ptr() != key:
+            _handoff_ws.pop(key, None)
+            continue
+        if torch.cuda.is_current_stream_capturing():
+            return
+        n = int(ws[SPLITK_ERROR_SLOT:SPLITK_ERROR_SLOT + 1].view(torch.int32).item())
+        if n:
+            ws[:SPLITK_FLAGS].zero_()
+            bad.append(n)
+    if bad:
+        raise nv.SevaNativeError(
+            f"split-K hand-off: {sum(bad)} consumer workgroup(s) gave up waiting for their producer; the outputs of the "
+            "affected launches are wrong (flags re-armed; rerun, or set SEVA_CONV_SPLITK=0)")
 
 
 def splitk_workspace(max_rows: int, max_channels: int, device) -> torch.Tensor:
@@ -176,6 +214,7 @@ def conv3x3(
     if splitk_ws is not None and not fp8:  # `splitk_workspace`: lets small-image convs run as split-K = 2 (seva_hip.h)
         assert splitk_ws.dtype == F32 and splitk_ws.is_contiguous()
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * 4
+        _register_handoff_ws(splitk_ws)
     if fp8:
         assert w_exp.dtype == U8 and w_exp.numel() == w.shape[0]
         d.w_exp = w_exp.data_ptr()
@@ -523,6 +562,7 @@ def prof_collect() -> dict:
     work = (C.c_double * nv.PROF_CLASSES)()
     nbytes = (C.c_double * nv.PROF_CLASSES)()
     check(_lib().seva_prof_collect(ms, n, work, nbytes), "seva_prof_collect")
+    check_handoffs()  # (prof_collect synchronises anyway)
     return {name: {"ms": ms[i], "launches": n[i], "work": work[i], "bytes": nbytes[i]}
             for i, name in enumerate(nv.PROF_NAMES)}
 

@@ -184,7 +184,7 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
     """Generate every non-input frame of a trajectory.  `denoise_net(x, t, cond, num_frames=T)` is the network call
     (`SGMWrapper(model)`); `input_latents` (n_in,4,h,w) are the VAE-encoded input views (x 0.18215), frame ids
     `input_ids` index `c2ws` (n,4,4) / `Ks` (n,3,3).  Returns, on rank 0, {"latents": (n,4,h,w) in frame order,
-    "frame_ids", "plan", ["rgb"]}; other ranks get {"plan"} only."""
+    "frame_ids", "plan", "anchor_latents" (first-pass anchors as pass 2 saw them), ["rgb"]}; other ranks get {"plan"} only."""
     rank, world = _rank_world(group)
     device = torch.device(device) if device is not None else input_latents.device
     h, w = input_latents.shape[-2:]
@@ -306,7 +306,9 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
             final[fid] = z[slot]
             filled[fid] = True
     assert bool(filled.all()), f"frames never generated: {torch.nonzero(~filled).flatten().tolist()}"
-    res = {"latents": final, "frame_ids": list(range(n)), "plan": plan}
+    # "anchor_latents": what pass 2 conditioned on (first-pass samples after the hand-off), whether or not pass 2 regenerated them
+    res = {"latents": final, "frame_ids": list(range(n)), "plan": plan,
+           "anchor_latents": {fid: latents_of[fid] for fid in plan.anchor_ids}}
     if ae is not None:
         res["rgb"] = ae.decode(final)
         mark("decode")

@@ -491,4 +491,8 @@ class EulerEDMSampler(object):
             )
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, scale, cond, uc,
                                   gamma, **guider_kwargs)
+        # once per trajectory, after the last step (never inside the loop): a split-K consumer that gave up waiting for its
+        # producer (csrc/gemm.hip) left a wrong tile behind -- make that an error instead of a silently wrong sample
+        if x.is_cuda:
+            ops.check_handoffs()
         return x

@@ -192,3 +192,62 @@ def test_full_50_step_loop_graph_equals_eager_at_576(dev, full, monkeypatch):
     assert torch.isfinite(a).all() and torch.equal(a, b)
     assert 1e-3 < float(a.abs().mean()) < 1e3
     print(f"\n50-step loop T=21 576x576: graph == eager bitwise; |x| mean {float(a.abs().mean()):.3f}")
+
+
+def test_reference_calling_contract_load_model_autocast_inference_mode(dev, full, tmp_path):
+    """How the reference actually drives the path (seva/eval.py:1242-1312 `do_sample`, seva/utils.py:29-56 `load_model`):
+    weights come from a safetensors directory as bf16 through `seva.utils.load_model` (meta-device construction +
+    `load_state_dict(assign=True)`), and the sampler runs under `torch.inference_mode()` AND `torch.autocast("cuda")`.
+    Result must be bit-equal to the plain run (fp32-stored weights of the same bf16-representable values, no autocast, no
+    inference mode): the HIP kernels take raw pointers and are not subject to autocast, and the host-sized torch ops inside the
+    step must not change the numbers either."""
+    import safetensors.torch
+    from seva import sampling as S
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+    from seva.utils import load_model
+    net_plain, sd = full
+    path = tmp_path / "ckpt"
+    path.mkdir()
+    safetensors.torch.save_file({k: v.to(torch.bfloat16).contiguous() for k, v in sd.items()}, str(path / "model.safetensors"))
+    with pytest.raises(FileNotFoundError):
+        load_model(str(tmp_path / "nowhere"))
+    model = load_model(str(path), device="cuda")
+    assert next(model.parameters()).dtype == torch.bfloat16 and next(model.parameters()).is_cuda
+    model.eval()
+    T, hw, steps = 4, 32, 3  # BASELINE config 1 shapes
+    sc = synth.synth_scene(T, (hw, hw), (0,), seed=23)
+    disc = S.DDPMDiscretization()
+    recorded = []
+
+    def run(net, contract):
+        den = S.DiscreteDenoiser(disc, num_idx=1000, device=dev)
+        sampler = S.EulerEDMSampler(disc, S.MultiviewCFG(1.2), num_steps=steps, verbose=False, device=dev, s_churn=0.0)
+        it = iter(recorded)
+        if contract:  # the eager first run recorded its per-step noise: replay it (the draw itself is torch's, not under test)
+            sampler.noise_fn = lambda x: next(it).clone()
+        else:
+            def draw(x):
+                e = torch.randn_like(x)
+                recorded.append(e.clone())
+                return e
+            sampler.noise_fn = draw
+        wrap = SGMWrapper(net)
+        args = dict(scale=2.0, verbose=False)
+
+        def go():
+            cond = {k: v.to(dev) for k, v in sc["cond"].items()}
+            uc = {k: v.to(dev) for k, v in sc["uc"].items()}
+            kw = dict(c2w=sc["c2w"].to(dev), K=sc["K"].to(dev), input_frame_mask=sc["input_frame_mask"].to(dev))
+            return sampler(lambda x, s, c: den(wrap, x, s, c, num_frames=T), sc["noise"].to(dev), cond=cond, uc=uc,
+                           **args, **kw).float().clone()
+        if contract:
+            with torch.inference_mode(), torch.autocast("cuda"):
+                return go()
+        return go()
+
+    a = run(net_plain, False)
+    b = run(model, True)
+    assert torch.isfinite(a).all() and a.shape == (T, 4, hw, hw)
+    print(f"\ncalling contract (load_model bf16 + inference_mode + autocast) vs plain: max |diff| {float((a - b).abs().max()):.3e}")
+    assert torch.equal(a, b)

@@ -116,6 +116,13 @@ def test_geglu_multi_tile_walk(dev, M, C, K, astat, knobs):
     assert torch.isfinite(o16).all() and rel_l2(o16, ref) < 1e-3
 
 
+def _need_exp_lib(what):
+    """Kernels that lost their A/B live only in build_ab/libseva_hip_exp.so (`make -C stable-virtual-camera_amd/csrc exp`,
+    loaded through SEVA_HIP_LIB): skipped against the production library, which does not carry them."""
+    if "exp" not in os.path.basename(os.environ.get("SEVA_HIP_LIB", "")):
+        pytest.skip(f"production libseva_hip.so does not carry {what} (experimental library only)")
+
+
 @pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 4, 64), (777, 960, 640), (4097, 132, 192)])
 def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg, knobs):
@@ -308,6 +315,8 @@ def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, knobs):
     the key sequence, keys that beat the running maximum by far more than the deferred-rescale threshold
     (rescale branch), and shifts all logits of the first tile far below zero (first-tile reference)."""
     from seva import ops
+    if two == "3":
+        _need_exp_lib("the software-pipelined attention kernel")
     knobs(attn_two=two)  # 0: attn_kernel everywhere, 1: the two-query-block kernel from Lq >= 512, 3: the software-pipelined kernel
     C = 64 * H
     g = torch.Generator().manual_seed(31)
@@ -577,13 +586,22 @@ def test_conv_splitk_small_images(dev, n, ih, iw, cin, cout, stride):
     bias, emb, res = _ints((cout,), -3, 3, dev, 3), _ints((n, cout), -2, 2, dev, 4), _ints((M, cout), -4, 4, dev, 5)
     wp = pack_conv3x3(wc).half().to(dev)
     o = torch.full((M, cout), float("nan"), device=dev)
-    for _ in range(2):  # twice through the same workspace
+    # a SECOND data set alternates with the first through the ONE workspace (a hand-off that consumed a stale or early partial
+    # would go unnoticed if every launch wrote the same partial tiles -- the pattern that once hid exactly that bug)
+    x2 = _ints((n, ih, iw, cin), -2, 2, dev, 11).half()
+    wc2 = _ints((cout, cin, 3, 3), -1, 1, dev, 12)
+    wp2 = pack_conv3x3(wc2).half().to(dev)
+    refs = []
+    for xx, ww in ((x, wc), (x2, wc2)):
+        r = F.conv2d(xx.float().permute(0, 3, 1, 2), ww, bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+        refs.append(r + emb.repeat_interleave(oh * ow, 0) + res)
+    for it in range(6):
         o.fill_(float("nan"))
-        ops.conv3x3(x, wp, stride=stride, bias=bias, row_add=emb, rows_per_group=oh * ow, residual=res, out_f32=o, splitk_ws=ws)
-        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wc, bias, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(M, cout)
-        ref = ref + emb.repeat_interleave(oh * ow, 0) + res
-        assert torch.equal(o, ref), f"max diff {(o - ref).abs().max()}"
-        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+        ops.conv3x3((x, x2)[it & 1], (wp, wp2)[it & 1], stride=stride, bias=bias, row_add=emb, rows_per_group=oh * ow,
+                    residual=res, out_f32=o, splitk_ws=ws)
+        assert torch.equal(o, refs[it & 1]), f"launch {it}: max diff {(o - refs[it & 1]).abs().max()}"
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0  # flags re-armed, error slot (16383) untouched
+    ops.check_handoffs()  # what the product calls at the end of a trajectory: raises if any consumer gave up
     xr, wr = _rand((n, ih, iw, cin), dev, 6).half(), (pack_conv3x3(_rand((cout, cin, 3, 3), dev, 7, 0.05).cpu()).half().to(dev))
     o1, o2 = torch.empty_like(o), torch.empty_like(o)
     ops.conv3x3(xr, wr, stride=stride, bias=bias, residual=res, out_f32=o1)
@@ -609,6 +627,7 @@ def test_streamk_bitwise_equal_to_unsplit(dev, kind, shape, knobs):
     that read stale or early data would go unnoticed if every launch wrote the same partial tiles)."""
     from seva import ops
     from seva._engine import pack_conv3x3
+    _need_exp_lib("the stream-K kernels")
 
     def case(seed):
         if kind == "gemm":
@@ -864,6 +883,8 @@ def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res, variant, knobs):
     replaces -- same f16 rounding of the hidden tensor, so they agree to fp32 accumulation-order noise -- and (b) fp32 torch."""
     from seva import ops
     from seva._engine import interleave_geglu
+    if variant == 4:
+        _need_exp_lib("the 4-wave fused feed-forward kernel")
     knobs(ff_variant=variant)  # 8 (default): two waves per row group; 4: one wave per row group, 512 registers
     g = torch.Generator().manual_seed(91)
     a = torch.randn(M, C, generator=g).half().to(dev)

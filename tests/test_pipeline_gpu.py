@@ -1,6 +1,7 @@
 """Two-pass trajectory driver (`seva.pipeline`, BASELINE config 4) on the HIP path, one GPU: a 50-view orbit through the tiny
-UNet -- every frame generated exactly once, the input frame untouched, deterministic, and window results independent of the
-execution order (what makes sharding over ranks a pure scheduling decision; the 2-rank run itself is tested on gloo)."""
+UNet and the FULL-SIZE 168-view plan through the 1.3B network at 576x576 -- every frame generated, the input frame untouched,
+deterministic, and window results independent of the execution order (what makes sharding over ranks a pure scheduling
+decision; the 2-rank run itself is tested on gloo)."""
 import pytest
 import torch
 
@@ -40,7 +41,7 @@ def test_trajectory_on_gpu_tiny(dev):
     assert torch.equal(a["latents"][0], lat[0])
     # a pass-2 window run on its own (as another rank would) reproduces its frames bit for bit
     win = plan.pass2[-1]
-    latents_of = {0: lat[0], **{f: a["latents"][f] for f in plan.anchor_ids}}
+    latents_of = {0: lat[0], **a["anchor_latents"]}
     g0 = torch.Generator().manual_seed(23)
     noises = [torch.randn((T, 4, hw, hw), generator=g0) for _ in range(len(plan.pass1) + len(plan.pass2))]
     with torch.no_grad():
@@ -49,3 +50,49 @@ def test_trajectory_on_gpu_tiny(dev):
                                 step_seed=(23 * 1000003 + 7919 * (win.global_index + 1)) & 0x7FFFFFFFFFFF, clip_token=tok, device=dev)
     for fid, slot in zip(win.target_ids, win.target_slots):
         assert torch.equal(z[slot], a["latents"][fid])
+
+
+def test_trajectory_168_views_full_size_one_gpu(dev):
+    """BASELINE config 4's workload on ONE GPU: the 168-view orbit (1 input view, the reference's two-pass plan: 20 anchors,
+    1 + 10 windows of 21 views) through the 1.3B network at 576x576 (latent 72x72), 2 sampler steps per window (the plan, the
+    window assembly, the anchor hand-off and the reassembly are step-count independent; 50 steps is `bench.py --trajectory 168`).
+    Every non-input frame is generated (anchors twice: pass 1, then again in pass 2 like the reference), everything finite,
+    and a second-pass window re-run on its own -- as another rank would run it -- reproduces its frames bit for bit."""
+    from test_model_gpu import _build
+    from seva import pipeline
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+    net, _ = _build("full", dev)
+    n, hw, T, steps = 168, 72, 21, 2
+    c2ws, Ks = synth.orbit_c2w(n), synth.default_K(n)
+    g = torch.Generator().manual_seed(23)
+    lat = (torch.randn(1, 4, hw, hw, generator=g) * 0.18215 * 5.0).to(dev)
+    tok = torch.randn(1024, generator=g)
+    tok = (tok / tok.norm()).to(dev)
+    wrap = SGMWrapper(net)
+    plan = pipeline.plan_trajectory(c2ws, [0], T=T)
+    assert len(plan.anchor_ids) == 20 and len(plan.pass1) == 1 and len(plan.pass2) == 10
+    assert sorted(f for w in plan.pass2 for f in w.target_ids) == list(range(1, n))
+    timers = {}
+    with torch.no_grad():
+        res = pipeline.run_trajectory(wrap, lat, c2ws, Ks, [0], clip_token=tok, T=T, num_steps=steps, device=dev, plan=plan,
+                                      timers=timers)
+    z = res["latents"]
+    assert z.shape == (n, 4, hw, hw) and torch.isfinite(z).all() and torch.equal(z[0], lat[0])
+    assert float(z[1:].abs().mean()) > 1e-3 and all(float(z[f].abs().max()) > 0 for f in range(1, n))
+    # anchors: final frames are second-pass samples, distinct from the first-pass ones pass 2 conditioned on
+    a0 = plan.anchor_ids[3]
+    assert not torch.equal(z[a0], res["anchor_latents"][a0])
+    win = plan.pass2[4]
+    latents_of = {0: lat[0], **res["anchor_latents"]}
+    g0 = torch.Generator().manual_seed(23)
+    noises = [torch.randn((T, 4, hw, hw), generator=g0) for _ in range(len(plan.pass1) + len(plan.pass2))]
+    with torch.no_grad():
+        zz = pipeline.run_window(win, latents_of, wrap, c2ws, Ks, hw=(hw, hw), num_steps=steps, cfg=2.0, cfg_min=1.2, guider=1,
+                                 camera_scale=2.0, noise=noises[win.global_index],
+                                 step_seed=(23 * 1000003 + 7919 * (win.global_index + 1)) & 0x7FFFFFFFFFFF, clip_token=tok,
+                                 device=dev)
+    for fid, slot in zip(win.target_ids, win.target_slots):
+        assert torch.equal(zz[slot], z[fid])
+    print(f"\n168-view trajectory, 1.3B @ 576x576, {steps} steps/window: {len(plan.pass1)}+{len(plan.pass2)} windows in "
+          f"{timers['gather'] - timers['start']:.2f} s")

@@ -196,8 +196,13 @@ static float run(const half_t* A, const half_t* W, long M, long N, long K, float
   return t[t.size() / 2];
 }
 
+static void need(long M, long N, long K) {
+  if (M * K > 54432L * 5760 || N * K > 10240L * 5120 || K % 128) { printf("shape exceeds the allocations\n"); exit(2); }
+}
+
 template <int BM, int BN, int NW>
 static void sweep(const char* name, const half_t* A, const half_t* W, long M, long N, long K, float* sink) {
+  need(M, N, K);
   const long tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   const double dma_bytes = (double)tm * tn * (BM + BN) * 2.0 * K;
   const double flops = 2.0 * M * N * K;
@@ -221,11 +226,152 @@ static void sweep(const char* name, const half_t* A, const half_t* W, long M, lo
   if constexpr (fit3) line("reads+MFMA + DMA  full stages, 3 buffers", run<BM, BN, NW, 3, 1>(A, W, M, N, K, sink, 5), true);
 }
 
+// VAR 5: the A operand never touches LDS.  Waves are stacked 4 x 1 (32 rows x the full 160-column tile each: the A-in-registers
+// layout of the production ASTAT kernel), the W tile is staged by LDS-DMA as before (2 buffers of 160 x 128 B), and every wave
+// loads the A fragments of the NEXT K-tile straight from global memory into a second register set (fragment-shaped: 16 rows x
+// 64 B per wave-instruction) while it computes on the current one.  LDS-DMA bytes per FLOP: 0.0078 instead of 0.0125 (160 x 160)
+// or 0.0141 (128 x 160 with A staged); bytes into the CU per FLOP 0.0137.
+template <int WORK>
+__global__ __launch_bounds__(256, 2) void k_adirect(const half_t* A, const half_t* W, long M, long N, long K, int tiles_m, int tiles_n,
+                                                    float* sink) {
+  constexpr int BM = 128, BN = 160, NW = 4, MI = 2, NJ = 10, P = BN / 8 / NW;  // 5 DMA pieces per wave and stage
+  constexpr int BUF_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int work = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = work / tiles_n, tn = work - tm * tiles_n;
+  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const half_t* src[P];
+  unsigned dst[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int id = wave + NW * i, r = id * 8 + (lane >> 3), q = (lane & 7) ^ ((r >> 1) & 7);
+    long g = n0 + r;
+    if (g >= N) g = N - 1;
+    src[i] = W + g * K + q * 8;
+    dst[i] = id * 1024;
+  }
+  const int fr = lane & 15, fg = lane >> 4;
+  const half_t* ap[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    long g = m0 + 32 * wave + 16 * i + fr;
+    if (g >= M) g = M - 1;
+    ap[i] = A + g * K + fg * 8;
+  }
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) glds16_raw(src[i] + (long)kt * 64, lds0 + buf * BUF_BYTES + dst[i]);
+  };
+  auto loadA = [&](half8_t (&a)[MI][2], int kt) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a[i][s] = *(const half8_t*)(ap[i] + (long)kt * 64 + s * 32);
+  };
+  auto compute = [&](const half8_t (&a)[MI][2], int buf) {
+    if (WORK == 0) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" ::"v"(a[i][s]));
+      return;
+    }
+    const char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8_t bf[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = 16 * j + fr;
+        bf[j] = *(const half8_t*)(base + r * 128 + (((4 * s + fg) ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], a[i][s], acc[i][j], 0, 0, 0);
+    }
+  };
+  auto sync = [&]() {
+    wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  const int nk = (int)(K / 64);  // even in every shape used here
+  half8_t a0[MI][2], a1[MI][2];
+  issue(0, 0);
+  loadA(a0, 0);
+  sync();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 1 < nk) { issue(kt + 1, 1); loadA(a1, kt + 1); }
+    compute(a0, 0);
+    sync();
+    if (kt + 1 < nk) {
+      if (kt + 2 < nk) { issue(kt + 2, 0); loadA(a0, kt + 2); }
+      compute(a1, 1);
+      sync();
+    }
+  }
+  if (sink) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) t += acc[i][j];
+    if (t[0] + t[1] + t[2] + t[3] == 12345.678f) sink[threadIdx.x] = t[0];
+  }
+}
+
+template <int WORK>
+static float run_adirect(const half_t* A, const half_t* W, long M, long N, long K, float* sink, int reps) {
+  constexpr int lds = 2 * 160 * 128;
+  auto fn = k_adirect<WORK>;
+  hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int tm = (int)((M + 127) / 128), tn = (int)((N + 159) / 160);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  std::vector<float> t;
+  for (int r = 0; r < reps + 1; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(fn, dim3(tm * tn), dim3(256), lds, 0, A, W, M, N, K, tm, tn, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (r) t.push_back(ms * 1e3f);
+  }
+  std::sort(t.begin(), t.end());
+  return t[t.size() / 2];
+}
+
+static void sweep_adirect(const char* name, const half_t* A, const half_t* W, long M, long N, long K, float* sink) {
+  need(M, N, K);
+  const long tm = (M + 127) / 128, tn = (N + 159) / 160;
+  const double dma = (double)tm * tn * 160 * 2.0 * K, direct = (double)tm * tn * 128 * 2.0 * K, flops = 2.0 * M * N * K;
+  printf("%s  M=%ld N=%ld K=%ld tile 128x160, A straight to registers (%ld tiles, %.2f GB LDS-DMA + %.2f GB direct)\n", name, M, N, K,
+         tm * tn, dma / 1e9, direct / 1e9);
+  const float t0 = run_adirect<0>(A, W, M, N, K, sink, 5), t1 = run_adirect<1>(A, W, M, N, K, sink, 5);
+  printf("   %-46s %8.1f us  %5.1f B/clk/CU into the CU (DMA part %.1f)\n", "loads only   W by LDS-DMA + A to VGPRs", t0,
+         (dma + direct) / (t0 * 1e-6) / 256.0 / 2.4e9, dma / (t0 * 1e-6) / 256.0 / 2.4e9);
+  printf("   %-46s %8.1f us  %5.1f B/clk/CU into the CU (DMA part %.1f)  %6.0f TFLOP/s\n", "reads+MFMA + W by LDS-DMA + A to VGPRs", t1,
+         (dma + direct) / (t1 * 1e-6) / 256.0 / 2.4e9, dma / (t1 * 1e-6) / 256.0 / 2.4e9, flops / (t1 * 1e-6) / 1e12);
+}
+
 int main() {
-  const long Mmax = 217728, Kmax = 5120;
+  setvbuf(stdout, nullptr, _IOLBF, 0);
+  const long Kmax = 5120;
   half_t *A, *W;
   float* sink;
-  hipMalloc(&A, Mmax * 1280 * 2);  // largest A used: 217728 x 1280
+  const long Aelems = 54432L * 5760;  // largest A used: 54432 x 5760 (> 217728 x 1280)
+  hipMalloc(&A, Aelems * 2);
   hipMalloc(&W, 10240 * Kmax * 2);
   hipMalloc(&sink, 4096);
   // random-ish fill (clock under load depends on the data): small integers scaled
@@ -233,17 +379,21 @@ int main() {
     std::vector<half_t> h(1 << 24);
     unsigned s = 12345;
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (half_t)(((int)(s >> 20) % 2001 - 1000) / 1000.0f); }
-    for (long off = 0; off < Mmax * 1280; off += (long)h.size())
-      hipMemcpy(A + off, h.data(), std::min<long>(h.size(), Mmax * 1280 - off) * 2, hipMemcpyHostToDevice);
+    for (long off = 0; off < Aelems; off += (long)h.size())
+      hipMemcpy(A + off, h.data(), std::min<long>(h.size(), Aelems - off) * 2, hipMemcpyHostToDevice);
     for (long off = 0; off < 10240 * Kmax; off += (long)h.size())
       hipMemcpy(W + off, h.data(), std::min<long>(h.size(), 10240 * Kmax - off) * 2, hipMemcpyHostToDevice);
   }
   sweep<160, 160, 4>("ds2 ff2 +res    ", A, W, 54432, 640, 2560, sink);
-  sweep<160, 160, 4>("ds2 attn_out    ", A, W, 54432, 640, 640, sink);
+  sweep_adirect("ds2 ff2 +res    ", A, W, 54432, 640, 2560, sink);
+  sweep_adirect("ds2 attn_out    ", A, W, 54432, 640, 640, sink);
   sweep<160, 160, 4>("ds4 ff2         ", A, W, 13608, 1280, 5120, sink);
-  sweep<160, 160, 4>("ds1 ff2         ", A, W, 217728, 320, 1280, sink);
+  sweep_adirect("ds4 ff2         ", A, W, 13608, 1280, 5120, sink);
+  sweep_adirect("ds1 ff2         ", A, W, 217728, 320, 1280, sink);
   sweep<160, 160, 4>("ds4 geglu-like  ", A, W, 13608, 10240, 1280, sink);
+  sweep_adirect("ds4 geglu-like  ", A, W, 13608, 10240, 1280, sink);
   sweep<128, 128, 4>("ds2 conv-like128", A, W, 54432, 640, 5760, sink);
+  sweep_adirect("ds2 conv-like   ", A, W, 54432, 640, 5760, sink);
   sweep<256, 128, 8>("ds2 ff2 8 waves ", A, W, 54432, 640, 2560, sink);
   sweep<256, 128, 8>("ds4 ff2 8 waves ", A, W, 13608, 1280, 5120, sink);
   sweep<192, 192, 8>("ds4 ff2 8w 192  ", A, W, 13608, 1280, 5120, sink);
