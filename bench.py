@@ -16,6 +16,12 @@ anchor latents that adjacent windows share.  value = (steps of all ranks) / max-
 Extra objects on the JSON line: `roofline` (dominant kernel class, algorithmic FLOP / HIP-event
 time measured live in one instrumented step) and `cpu_baseline` (the CPU oracle timed on the
 host cores on BASELINE config 1, rank 0, N=1 only).
+
+Outside `value`, so that the driver-run record also carries BASELINE.json's other configurations:
+`other_configs` (N = 1: config 2 = T=8, config 3 = T=24 as one window, config 5 = fp8 at T=21, config 4 = the 168-view
+two-pass trajectory on this one GPU with a few sampler steps per window) and, for N > 1, `trajectory`: the SAME 168-view
+trajectory run across the N ranks with CFG-split (STRONG scaling: total work fixed; seva/pipeline.py) -- the number that
+says something about config 4, which one-window-per-rank weak scaling does not.
 """
 
 from __future__ import annotations
@@ -124,12 +130,46 @@ def cpu_baseline(sd):
 def trajectory_mode(args, net, device, rank, world):
     """BASELINE config 4: an N-view orbit, 1 input view, two-pass `interp` plan (1 + 10 windows of 21 views at N=168),
     50 steps per window.  Reports BOTH definitions SURVEY §8e names: the shardable second-pass throughput and the
-    whole-trajectory wall time including the serial first pass, the anchor all-gather and the gather to rank 0."""
+    whole-trajectory wall time including the first pass, the anchor all-gather and the gather to rank 0."""
+    leg = trajectory_leg(net, device, rank, world, args.trajectory, args.latent, args.views, args.traj_steps,
+                         not args.no_cfg_split)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"novel views/sec, 1.3B Seva, {leg['workload']}",
+            "value": leg["novel_views_per_sec"], "unit": "novel views/s (whole trajectory, first pass included)",
+            "higher_is_better": True, "dtype": "f16", "data": "synthetic", **leg}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def steps_leg(net, device, T, hw, steps, seed=23):
+    """steps/s of one window shape with the same procedure as the headline line (2 set-up steps incl. graph capture,
+    1 warm-up, `steps` timed), for the `other_configs` object."""
+    sampler, denoise, noise, cond, uc, gk = make_sampler(net, device, T, hw, steps + 3, seed)
+    x, s_in, sigmas, _, cond, uc = sampler.prepare_sampling_loop(noise, cond, uc, None)
+    with torch.no_grad():
+        for i in range(3):
+            x = sampler.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoise, x, 2.0, cond, uc, 0.0, **gk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, 3 + steps):
+            x = sampler.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoise, x, 2.0, cond, uc, 0.0, **gk)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(x).all()
+    flop = FLOP_PER_STEP.get((T, hw))
+    return {"views": T, "latent": hw, "steps": steps, "steps_per_sec": steps / dt, "ms_per_step": dt / steps * 1e3,
+            "model_tflops": flop * steps / dt / 1e12 if flop else None,
+            "hipgraph_whole_step": sampler._step_graphs.captures > 0}
+
+
+def trajectory_leg(net, device, rank, world, n, hw, T, steps, cfg_split):
+    """The n-view orbit (BASELINE config 4: n = 168 -> 20 anchors, 1 + 10 windows of 21 views) through
+    seva.pipeline.run_trajectory on `world` ranks, `steps` sampler steps per window.  Max-over-ranks phase times."""
     from seva import pipeline
     from seva import synthetic as synth
     from seva.model import SGMWrapper
 
-    n, hw, T = args.trajectory, args.latent, args.views
     c2ws, Ks = synth.orbit_c2w(n), synth.default_K(n)
     g = torch.Generator().manual_seed(23)
     lat = (torch.randn(1, 4, hw, hw, generator=g) * 0.18215 * 5.0).to(device)
@@ -139,15 +179,21 @@ def trajectory_mode(args, net, device, rank, world):
     plan = pipeline.plan_trajectory(c2ws, [0], T=T)
     timers: dict = {}
     with torch.no_grad():
-        # untimed warm-up: one short window fills the engine arena and every lazily packed weight on each rank
+        # untimed warm-up: one short window fills the engine arena on each rank (and, under CFG-split, the half-batch arena)
         pipeline.run_window(plan.pass2[0], {f: lat[0] for f in range(n)}, wrap, c2ws, Ks, hw=(hw, hw), num_steps=2, cfg=2.0,
                             cfg_min=1.2, guider=1, camera_scale=2.0, noise=torch.randn(T, 4, hw, hw), step_seed=1,
                             clip_token=tok, device=device)
+        if world > 1 and cfg_split:
+            pair = pipeline.cfg_pair_groups()[rank // 2] if rank // 2 < world // 2 else None
+            if pair is not None:
+                pipeline.run_window(plan.pass2[0], {f: lat[0] for f in range(n)}, wrap, c2ws, Ks, hw=(hw, hw), num_steps=2,
+                                    cfg=2.0, cfg_min=1.2, guider=1, camera_scale=2.0, noise=torch.randn(T, 4, hw, hw),
+                                    step_seed=1, clip_token=tok, device=device, cfg_split=(pair, rank % 2))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        res = pipeline.run_trajectory(wrap, lat, c2ws, Ks, [0], clip_token=tok, T=T, num_steps=args.traj_steps,
-                                      device=device, plan=plan, timers=timers)
+        res = pipeline.run_trajectory(wrap, lat, c2ws, Ks, [0], clip_token=tok, T=T, num_steps=steps, device=device,
+                                      plan=plan, timers=timers, cfg_split=cfg_split and world > 1)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -159,19 +205,18 @@ def trajectory_mode(args, net, device, rank, world):
     p1, ex, p2, ga, total = (float(v) for v in t)
     if rank == 0:
         assert torch.isfinite(res["latents"]).all()
-        steps2 = len(plan.pass2) * args.traj_steps
-        print(json.dumps({
-            "metric": f"novel views/sec, 1.3B Seva, {n}-view orbit in {len(plan.pass1)}+{len(plan.pass2)} windows of {T} views "
-                      f"@ {hw * 8}x{hw * 8} (BASELINE config 4)",
-            "value": (n - 1) / total, "unit": "novel views/s (whole trajectory, first pass included)",
-            "n_gpus": world, "higher_is_better": True, "scaling": "strong", "dtype": "f16", "data": "synthetic",
-            "wall_s": total, "pass1_s": p1, "anchor_allgather_s": ex, "pass2_s": p2, "gather_s": ga,
-            "pass2_steps_per_sec": steps2 / p2, "pass2_windows": len(plan.pass2), "pass1_windows": len(plan.pass1),
-            "steps_per_window": args.traj_steps, "anchors": len(plan.anchor_ids),
-            "handoff": "anchor latents (no decode/encode round trip); VAE decode of the 167 frames not included",
-        }), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    sched = pipeline.second_pass_schedule(len(plan.pass2), world, cfg_split and world > 1)
+    return {
+        "workload": f"{n}-view orbit, 1 input view, reference two-pass plan: {len(plan.anchor_ids)} anchors, {len(plan.pass1)}+"
+                    f"{len(plan.pass2)} windows of {T} views @ {hw * 8}x{hw * 8}, {steps} sampler steps per window "
+                    f"(BASELINE config 4 runs 50), anchors regenerated in pass 2 like the reference",
+        "n_gpus": world, "scaling": "strong", "cfg_split": bool(cfg_split and world > 1), "steps_per_window": steps,
+        "wall_s": total, "novel_views_per_sec": (n - 1) / total, "pass1_s": p1, "anchor_allgather_s": ex, "pass2_s": p2,
+        "gather_s": ga, "pass2_steps_per_sec": len(plan.pass2) * steps / p2, "pass2_rounds": [len(r) for r in sched],
+        "window_times_ceiling": (0.5 if (cfg_split and world > 1) else 1.0) * len(plan.pass1)
+                                + sum(0.5 if len(r[0][1]) == 2 else 1.0 for r in sched),
+        "handoff": "anchor latents (no decode/encode round trip); VAE decode of the frames not included",
+    }
 
 
 def main():
@@ -185,12 +230,19 @@ def main():
                     help="BASELINE config 4 mode: generate an N-view orbit (1 input view) with the two-pass pipeline "
                          "(seva/pipeline.py), windows sharded over the ranks; prints its own JSON line")
     ap.add_argument("--traj-steps", type=int, default=50, help="sampler steps per window in --trajectory mode")
+    ap.add_argument("--no-cfg-split", action="store_true",
+                    help="--trajectory with N > 1: whole windows per rank only (no CFG-split of the first pass / leftover round)")
     ap.add_argument("--precision", choices=["f16", "fp8"], default="f16",
                     help="f16 = parity mode (default, the headline line); fp8 = BASELINE config 5: e4m3 weights + activations "
                          "on the block-scaled fp8 MFMA for the C >= 640 levels (separate accuracy class)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` legs (N = 1) / the strong-scaling `trajectory` leg (N > 1)")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each `other_configs` steps/s leg")
+    ap.add_argument("--leg-traj-steps", type=int, default=4,
+                    help="sampler steps per window of the 168-view trajectory legs on the default line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -224,6 +276,7 @@ def main():
         return trajectory_mode(args, net, device, rank, world)
     total_steps = K + Wm
     sampler, denoise, noise, cond, uc, gk = make_sampler(net, device, T, hw, max(total_steps, 2), 23 + rank)
+    cond_assembly_ms = getattr(make_sampler, "cond_assembly_ms", None)  # (of the headline window; later legs overwrite the attribute)
 
     # anchors shared by adjacent windows (first-pass output; here: this rank's input-view latent)
     anchors = cond["replace"][:1, :4].contiguous()
@@ -344,6 +397,22 @@ def main():
         vae["clip_conditioner_ms_per_frame"] = (time.perf_counter() - t1) * 1e3
         del clip
 
+    other, traj = None, None
+    if not args.no_other_configs and (T, hw) == (21, 72) and args.precision == "f16":
+        if world == 1:
+            # BASELINE configs 2, 3, 5 and (on this one GPU) 4 -- outside `value`
+            other = {"config2_T8": steps_leg(net, device, 8, hw, args.other_steps),
+                     "config3_T24_one_window": steps_leg(net, device, 24, hw, args.other_steps)}
+            net.set_precision("fp8")
+            leg = steps_leg(net, device, T, hw, args.other_steps)
+            leg["dtype"] = "f8e4m3 (C>=640 levels) + f16 (C=320 level); separate accuracy class, not the parity mode"
+            other["config5_fp8_T21"] = leg
+            net.set_precision("f16")
+            other["config4_trajectory168_one_gpu"] = trajectory_leg(net, device, rank, world, 168, hw, T,
+                                                                    args.leg_traj_steps, False)
+        else:
+            traj = trajectory_leg(net, device, rank, world, 168, hw, T, args.leg_traj_steps, True)
+
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -370,7 +439,8 @@ def main():
                        "flop_per_step": flop,
                        "model_tflops": (flop * value / 1e12) if flop else None},
             "roofline": roofline, "cpu_baseline": cpu, "vae_decode": vae,
-            "cond_assembly": {"ms": getattr(make_sampler, "cond_assembly_ms", None),
+            "other_configs": other, "trajectory": traj,
+            "cond_assembly": {"ms": cond_assembly_ms,
                               "what": "camera normalisation (host) + Pluecker maps + cond/uc assembly (HIP), once per window, outside `value`; median of 3"},
         }
         print(json.dumps(out), flush=True)

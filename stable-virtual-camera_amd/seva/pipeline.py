@@ -10,6 +10,12 @@ package's parts, one process per GPU:
     pass 2   windows read only {input views, anchors} (eval.py:1890-1906): independent units, `shard_windows`
     gather   finished window latents to rank 0 (round by round), reassembled in target order, optionally VAE-decoded
 
+CFG-split (`cfg_split=True`): strong scaling of ONE window over a PAIR of ranks -- rank 2j runs the
+unconditional half of every CFG batch, rank 2j+1 the conditional half, one 435 KB all-gather per step
+(`EulerEDMSampler.cfg_split`).  Used where whole windows cannot fill the ranks: the serial first pass (pair 0) and the
+leftover second-pass round (10 windows on 8 GPUs: 8 whole windows, then the last 2 on pairs (0,1), (2,3)):
+168 views on 8 GPUs = 0.5 + 1 + 0.5 window times instead of 1 + 2 (ceiling 5.5x instead of 3.7x).  Bitwise the same trajectory.
+
 Hand-off between the passes: the reference carries the anchors across the pass boundary as decoded RGB and re-encodes
 them per window (eval.py:1820-1829, 1246).  Here the default hand-off is the anchor LATENT itself (`handoff="latent"`:
 no decode -> encode round trip, 1.66 MB instead of 40 MB on the wire); `handoff="rgb"` reproduces the reference's
@@ -144,9 +150,39 @@ def _all_gather_padded(local: torch.Tensor, count: int, max_count: int, group=No
     return list(out.view(world, max_count, *local.shape[1:]).unbind(0))
 
 
+_pair_groups: dict = {}
+
+
+def cfg_pair_groups(group=None) -> list:
+    """Two-rank process groups (0,1), (2,3), ... of `group` (default: the world), created once per process: every rank
+    calls this (new_group is collective) and gets the same list; entry j is the group of ranks 2j and 2j+1."""
+    rank, world = _rank_world(group)
+    key = (id(group), world)
+    if key not in _pair_groups:
+        ranks = list(range(world)) if group is None else dist.get_process_group_ranks(group)
+        _pair_groups[key] = [dist.new_group([ranks[2 * j], ranks[2 * j + 1]]) for j in range(world // 2)]
+    return _pair_groups[key]
+
+
+def second_pass_schedule(n_windows: int, world: int, cfg_split: bool) -> list[list[tuple]]:
+    """Rounds of (window index, ranks) for the second pass.  Whole-window rounds: window r*world + q on rank q.  With
+    `cfg_split`, a last round of L <= world/2 leftover windows runs window j on the pair (2j, 2j+1)."""
+    rounds, i = [], 0
+    while i < n_windows:
+        left = n_windows - i
+        if cfg_split and world >= 2 and left <= world // 2:
+            rounds.append([(i + j, (2 * j, 2 * j + 1)) for j in range(left)])
+            i += left
+        else:
+            k = min(left, world)
+            rounds.append([(i + q, (q,)) for q in range(k)])
+            i += k
+    return rounds
+
+
 def run_window(win: Window, latents_of: dict, denoise_net: Callable, c2ws, Ks, *, hw, num_steps, cfg, cfg_min, guider,
                camera_scale, noise: torch.Tensor, step_seed: int, clip_token: torch.Tensor, device,
-               sampler_hook: Callable | None = None) -> torch.Tensor:
+               sampler_hook: Callable | None = None, cfg_split: tuple | None = None) -> torch.Tensor:
     """One window = the reference's get_value_dict + do_sample (eval.py:1152-1321) on this package's parts.
     `latents_of[frame_id]` -> (4,h,w) latent of every conditioning frame.  Returns the (T,4,h,w) sample."""
     T = len(win.slot_frame)
@@ -165,6 +201,7 @@ def run_window(win: Window, latents_of: dict, denoise_net: Callable, c2ws, Ks, *
     gen = torch.Generator(device=device)
     gen.manual_seed(int(step_seed))
     sampler.noise_fn = lambda x: torch.randn(x.shape, generator=gen, device=x.device, dtype=x.dtype)
+    sampler.cfg_split = cfg_split  # (two-rank group, half): both ranks draw the same per-step noise from `step_seed`
     if sampler_hook is not None:
         sampler_hook(sampler)
     kw = {} if guider == 0 else dict(c2w=vd["c2w"].to(device), K=Ks[frames].to(device), input_frame_mask=mask.to(device))
@@ -180,7 +217,7 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
                    handoff: str = "latent",
                    plan: TrajectoryPlan | None = None, timers: dict | None = None,
                    sampler_hook: Callable | None = None, conditioner: Callable | None = None,
-                   input_rgb: torch.Tensor | None = None) -> dict:
+                   input_rgb: torch.Tensor | None = None, cfg_split: bool = False) -> dict:
     """Generate every non-input frame of a trajectory.  `denoise_net(x, t, cond, num_frames=T)` is the network call
     (`SGMWrapper(model)`); `input_latents` (n_in,4,h,w) are the VAE-encoded input views (x 0.18215), frame ids
     `input_ids` index `c2ws` (n,4,4) / `Ks` (n,3,3).  Returns, on rank 0, {"latents": (n,4,h,w) in frame order,
@@ -233,31 +270,38 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
         return z
 
     mark("start")
+    pairs = cfg_pair_groups(group) if (cfg_split and world >= 2) else []
     # ------------------------------------------------------------------ pass 1
-    mine1 = list(range(len(plan.pass1))) if world == 1 else (
-        ([i for i in range(len(plan.pass1))] if rank == 0 else []) if plan.pass1_serial
-        else shard_windows(len(plan.pass1), rank, world))
+    # serial strategies (and, under cfg_split, every first pass): pair 0 = ranks (0, 1) splits the CFG batch of each window
+    split1 = bool(pairs) and (plan.pass1_serial or len(plan.pass1) == 1)
+    if split1:
+        mine1 = list(range(len(plan.pass1))) if rank < 2 else []
+    else:
+        mine1 = list(range(len(plan.pass1))) if world == 1 else (
+            ([i for i in range(len(plan.pass1))] if rank == 0 else []) if plan.pass1_serial
+            else shard_windows(len(plan.pass1), rank, world))
     got_ids, got_lat = [], []
     for i in mine1:
         win = plan.pass1[i]
         z = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index], step_seed=step_seed(win),
-                       clip_token=tok(win.source_ids), **common)
+                       clip_token=tok(win.source_ids), cfg_split=(pairs[0], rank) if split1 else None, **common)
         zt = handoff_latent(z[win.target_slots], win.target_ids)
         for fid, lat in zip(win.target_ids, zt):
             latents_of[fid] = lat  # a dependent strategy's next window on this rank may read it
-            got_ids.append(fid)
-            got_lat.append(lat)
+            if not (split1 and rank == 1):  # (rank 1 of the pair holds the same bits; rank 0 is the owner that publishes them)
+                got_ids.append(fid)
+                got_lat.append(lat)
     mark("pass1")
     # ------------------------------------------------------------------ exchange: one all-gather of the anchors
     counts = [0] * world
     for i, win in enumerate(plan.pass1):
-        owner = 0 if (world == 1 or plan.pass1_serial) else i % world
+        owner = 0 if (world == 1 or plan.pass1_serial or split1) else i % world
         counts[owner] += len(win.target_ids)
     local = torch.stack(got_lat) if got_lat else torch.zeros((0, 4, h, w), device=device)
     parts = _all_gather_padded(local.to(device=device, dtype=torch.float32), counts[rank], max(max(counts), 1), group)
     owner_ids = [[] for _ in range(world)]
     for i, win in enumerate(plan.pass1):
-        owner_ids[0 if (world == 1 or plan.pass1_serial) else i % world].extend(win.target_ids)
+        owner_ids[0 if (world == 1 or plan.pass1_serial or split1) else i % world].extend(win.target_ids)
     for r in range(world):
         for j, fid in enumerate(owner_ids[r]):
             latents_of[fid] = parts[r][j]
@@ -267,30 +311,32 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
                 rgb_of[fid] = ae.decode(latents_of[fid][None])[0]
     mark("exchange")
     # ------------------------------------------------------------------ pass 2: independent windows, sharded
-    mine2 = shard_windows(len(plan.pass2), rank, world)
+    sched = second_pass_schedule(len(plan.pass2), world, bool(pairs))
     outs = {}
-    for i in mine2:
-        win = plan.pass2[i]
-        outs[i] = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index],
-                             step_seed=step_seed(win), clip_token=tok(win.source_ids), **common)
+    for rnd in sched:
+        for i, ranks in rnd:
+            if rank not in ranks:
+                continue
+            win = plan.pass2[i]
+            outs[i] = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index],
+                                 step_seed=step_seed(win), clip_token=tok(win.source_ids),
+                                 cfg_split=(pairs[ranks[0] // 2], ranks.index(rank)) if len(ranks) == 2 else None, **common)
     mark("pass2")
     # ------------------------------------------------------------------ gather to rank 0, round by round
-    rounds = (len(plan.pass2) + world - 1) // world
     collected = {}
-    for r in range(rounds):
-        i = r * world + rank
-        mine = outs.get(i)
+    for rnd in sched:
+        sender = {ranks[0]: i for i, ranks in rnd}  # a pair's even rank sends (both hold the same bits)
+        mine = outs.get(sender[rank]) if rank in sender else None
         if world == 1:
             if mine is not None:
-                collected[i] = mine
+                collected[sender[rank]] = mine
             continue
         send = mine if mine is not None else torch.zeros((plan.T, 4, h, w), device=device)
         bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
         dist.gather(send.contiguous(), bufs, dst=0, group=group)
         if rank == 0:
-            for rr in range(world):
-                if r * world + rr < len(plan.pass2):
-                    collected[r * world + rr] = bufs[rr]
+            for rr, i in sender.items():
+                collected[i] = bufs[rr]
     mark("gather")
     if rank != 0:
         return {"plan": plan}

@@ -367,6 +367,13 @@ class EulerEDMSampler(object):
         self.s_noise = s_noise
         self.noise_fn = torch.randn_like  # injectable: fn(x) -> N(0,1) tensor like x
         self._step_graphs = _stepgraph.StepGraphCache()
+        # CFG-split (strong scaling of ONE window over two GPUs): (process group of two ranks, half) with
+        # half = this rank's position in the group: 0 runs the unconditional half of the CFG batch, 1 the conditional half.
+        # Each step the two ranks all-gather their (T,4,h,w) denoised halves (435 KB at 576x576 over xGMI) and then both
+        # perform the identical guidance + Euler update, so both hold the full sampler state; the per-step noise must come
+        # from identically seeded generators on both ranks (`noise_fn`; seva.pipeline does that).  None = the whole CFG batch
+        # on this rank (the reference's single-process semantics, sampling.py:231-242).
+        self.cfg_split: tuple | None = None
 
     def prepare_sampling_loop(self, x: torch.Tensor, cond: dict, uc: dict, num_steps: int | None = None):
         num_steps = num_steps or self.num_steps
@@ -403,7 +410,10 @@ class EulerEDMSampler(object):
         noise_scale = (sigma_hat**2 - sigma**2) ** 0.5 * self.s_noise
         x_noised = torch.empty_like(x)
         ops.add_noise(x, eps, _f32c(noise_scale), x_noised)
-        denoised2 = denoiser(*self.guider.prepare_inputs(x_noised, sigma_hat, cond, uc))
+        if self.cfg_split is None:
+            denoised2 = denoiser(*self.guider.prepare_inputs(x_noised, sigma_hat, cond, uc))
+        else:
+            denoised2 = self._denoise_cfg_split(denoiser, x_noised, sigma_hat, cond, uc)
         dt = next_sigma - sigma_hat
         out = torch.empty_like(x)
         if hasattr(self.guider, "frame_scale"):
@@ -415,6 +425,24 @@ class EulerEDMSampler(object):
             denoised = self.guider(denoised2, sigma_hat, scale, **guider_kwargs)
             ops.euler_step(x_noised, _f32c(denoised), sigma_hat, dt, out)
         return out
+
+    def _denoise_cfg_split(self, denoiser, x_noised, sigma_hat, cond, uc):
+        """[uncond ; cond] denoised latents with each half of the CFG batch computed by one rank of `cfg_split`'s
+        two-rank group and exchanged by ONE all-gather (rank order of the group = batch order of
+        `VanillaCFG.prepare_inputs`, reference sampling.py:231-242).  Every row of the network's output depends only on
+        the rows of its own scene, and the kernels' tilings are chosen from per-sample sizes, so the half batch is bitwise
+        the corresponding half of the full batch."""
+        import torch.distributed as dist
+
+        group, half = self.cfg_split
+        xx, ss, cc = self.guider.prepare_inputs(x_noised, sigma_hat, cond, uc)
+        n = x_noised.shape[0]
+        sl = slice(half * n, (half + 1) * n)
+        cc_half = {k: (v[sl] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == 2 * n else v) for k, v in cc.items()}
+        mine = _f32c(denoiser(xx[sl], ss[sl], cc_half))
+        both = torch.empty((2 * n,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(both, mine, group=group)
+        return both
 
     @staticmethod
     def _flat_key(obj):
@@ -444,7 +472,9 @@ class EulerEDMSampler(object):
         eps = _f32c(self.noise_fn(x))  # drawn eagerly: the generator advances per step exactly as in the reference
         gamma = float(gamma)
         cache = self._step_graphs
-        use_graph = (x.is_cuda and not cache.disabled and _stepgraph.enabled()
+        # (CFG-split steps are not captured as one graph: the per-step all-gather runs eagerly between the two ranks;
+        #  the network call itself is still replayed from its own hipGraph)
+        use_graph = (x.is_cuda and not cache.disabled and _stepgraph.enabled() and self.cfg_split is None
                      and not torch.cuda.is_current_stream_capturing())
         if not use_graph:
             return self._step_math(sigma, next_sigma, x, eps, denoiser, scale, cond, uc, gamma, guider_kwargs)

@@ -44,9 +44,9 @@ def _fake_net(x, t, cond, num_frames):
     return 0.3 * x + 0.2 * mix + 0.05 * cond["concat"][:, 1:5] + 0.01 * cond["concat"][:, :1] + 1e-4 * t.view(-1, 1, 1, 1).float()
 
 
-def _run(group=None, **kw):
+def _run(group=None, n=168, **kw):
     from seva import pipeline
-    c2ws, Ks, lat, tok = _scene()
+    c2ws, Ks, lat, tok = _scene(n)
     return pipeline.run_trajectory(_fake_net, lat, c2ws, Ks, [0], clip_token=tok, T=21, num_steps=3, seed=23,
                                    device="cpu", group=group, **kw)
 
@@ -102,13 +102,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, first_pass):
+def _worker(rank, world, port, q, first_pass, extra=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _patch_cpu()
     timers = {}
-    res = _run(first_pass_strategy=first_pass, timers=timers)
+    res = _run(first_pass_strategy=first_pass, timers=timers, **(extra or {}))
     q.put((rank, res["latents"].numpy() if "latents" in res else None, sorted(timers)))
     dist.destroy_process_group()
 
@@ -173,3 +173,54 @@ def test_reference_style_rgb_handoff_and_per_window_clip_token(monkeypatch):
                                   handoff="rgb", conditioner=fake_clip, input_rgb=rgb_in, refine_anchors=False)
     a = res["plan"].anchor_ids[0]
     assert torch.allclose(res["latents"][a][3], res["latents"][a][:3].mean(0) / 1.5, atol=1e-6)
+
+
+def test_second_pass_schedule_with_cfg_split():
+    """10 windows on 8 ranks: one round of 8 whole windows, then the 2 leftover windows on the pairs (0,1) and (2,3); without
+    cfg_split two whole-window rounds.  Every window exactly once; a pair is two adjacent ranks, even rank first."""
+    from seva.pipeline import second_pass_schedule
+    s = second_pass_schedule(10, 8, True)
+    assert [len(r) for r in s] == [8, 2] and s[1] == [(8, (0, 1)), (9, (2, 3))]
+    assert second_pass_schedule(10, 8, False) == [[(i, (i,)) for i in range(8)], [(8, (0,)), (9, (1,))]]
+    for n in range(1, 40):
+        for world in (1, 2, 4, 6, 8):
+            for split in (False, True):
+                sch = second_pass_schedule(n, world, split)
+                assert sorted(i for r in sch for i, _ in r) == list(range(n))
+                for r in sch:
+                    used = [q for _, ranks in r for q in ranks]
+                    assert len(used) == len(set(used)) and all(0 <= q < world for q in used)
+                    assert all(len(ranks) == 1 or (ranks[0] % 2 == 0 and ranks[1] == ranks[0] + 1) for _, ranks in r)
+    # ceiling of BASELINE config 4 on 8 GPUs in window times: 1 + 2 without, 0.5 + 1 + 0.5 with CFG-split
+    assert sum(0.5 if len(r[0][1]) == 2 else 1.0 for r in second_pass_schedule(10, 8, True)) == 1.5
+
+
+@pytest.mark.parametrize("world,n", [(2, 100), (4, 168)])
+def test_cfg_split_trajectory_equals_single_process(world, n, monkeypatch):
+    """CFG-split: the first-pass window on the pair (0,1) and the leftover second-pass round on pairs,
+    each rank of a pair running one half of every CFG batch with one all-gather per step -- the trajectory is bit for bit
+    the single-process one (gloo; world 2: an odd number of second-pass windows so that the last one is split;
+    world 4: the 168-view plan, 10 windows = 4 + 4 + a pair round of 2)."""
+    from conftest import PKG
+    from seva import pipeline
+    here = os.path.dirname(os.path.abspath(__file__))
+    os.environ["PYTHONPATH"] = os.pathsep.join([PKG, here, os.environ.get("PYTHONPATH", "")])
+    _patch_cpu(monkeypatch)
+    c2ws, _, _, _ = _scene(n)
+    n2 = len(pipeline.plan_trajectory(c2ws, [0], T=21).pass2)
+    sched = pipeline.second_pass_schedule(n2, world, True)
+    assert any(len(ranks) == 2 for r in sched for _, ranks in r), (n2, sched)
+    ref = _run(n=n)["latents"]
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "gt-nearest", dict(n=n, cfg_split=True))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = torch.from_numpy(res[0][1])
+    assert all(r[1] is None for r in res[1:])
+    assert torch.equal(got, ref), float((got - ref).abs().max())

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 typedef _Float16 half_t;
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -365,6 +366,188 @@ static void sweep_adirect(const char* name, const half_t* A, const half_t* W, lo
          (dma + direct) / (t1 * 1e-6) / 256.0 / 2.4e9, dma / (t1 * 1e-6) / 256.0 / 2.4e9, flops / (t1 * 1e-6) / 1e12);
 }
 
+// VAR 6 ("ping-pong"): ONE 8-wave workgroup per CU, ring of THREE full stages (two in flight), the waves in two groups of four
+// (waves 0-3 / 4-7: one wave of each group per SIMD) that run the same program ONE PHASE APART: while group 0 multiplies K-tile k
+// (M phase: MFMAs only, fragments already in registers) group 1 reads its fragments of K-tile k out of LDS and issues its share
+// of stage k+2 (R phase), and vice versa; one workgroup barrier per phase.  Stage k+2 goes into the buffer of stage k-1, which
+// both groups have finished reading one barrier earlier; a wave waits for its pieces of stage k+1 (counted vmcnt: stage k+2 stays
+// in flight) at the end of phase 2k+1, one barrier before group 0 reads them.  SPLIT of a wave's DMA pieces are issued inside
+// its M phase (between the MFMAs) instead of its R phase.
+template <int BM, int BN, int WORK, int SPLIT>
+__global__ __launch_bounds__(512, 1) void k_pingpong(const half_t* A, const half_t* W, long M, long N, long K, int tiles_m, int tiles_n,
+                                                     float* sink) {
+  constexpr int TP = (BM + BN) / 8;                  // DMA pieces per stage
+  constexpr int PMAX = (TP + 7) / 8;
+  constexpr int BUF_BYTES = (BM + BN) * 128;
+  constexpr int WM = BM / 4, WN = BN / 2, MI = WM / 16, NJ = WN / 16;
+  static_assert(TP % 8 == 0 || TP % 8 == 4, "pieces: equal inside a group of four waves");
+  static_assert(3 * BUF_BYTES <= 160 * 1024, "three stages must fit");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wq = wave & 3;
+  const int row0 = grp * (BM / 2) + (wq >> 1) * WM, col0 = (wq & 1) * WN;  // the wave's output tile
+  const int work = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = work / tiles_n, tn = work - tm * tiles_n;
+  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const half_t* src[PMAX];
+  unsigned dst[PMAX];
+#pragma unroll
+  for (int i = 0; i < PMAX; ++i) {
+    int id = wave + 8 * i;
+    if (id >= TP) id = TP - 1;  // (never issued: the group's piece count excludes it)
+    const int row = id * 8 + (lane >> 3), pc = lane & 7;
+    const bool isA = row < BM;
+    const int r = isA ? row : row - BM;
+    const int q = pc ^ ((r >> 1) & 7);
+    long g = isA ? m0 + r : n0 + r;
+    const long lim = isA ? M : N;
+    if (g >= lim) g = lim - 1;
+    src[i] = (isA ? A : W) + g * K + q * 8;
+    dst[i] = id * 1024;
+  }
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8_t af[2][MI], bf[2][NJ];
+  const int nk = (int)(K / 64);
+  auto barrier = [&]() {  // phase boundary: nothing (MFMAs included) may be scheduled across it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  auto body = [&](auto gtag) {
+    constexpr int G = decltype(gtag)::value;
+    constexpr int PG = (TP % 8 == 0) ? TP / 8 : (G == 0 ? TP / 8 + 1 : TP / 8);  // this group's pieces per stage
+    constexpr int SP = SPLIT < PG ? SPLIT : PG;                                      // issued in the M phase
+    auto issue = [&](int kt, int i0, int i1) {
+      int buf = kt % 3;
+#pragma unroll
+      for (int i = 0; i < PMAX; ++i)
+        if (i >= i0 && i < i1) glds16_raw(src[i] + (long)kt * 64, lds0 + buf * BUF_BYTES + dst[i]);
+    };
+    auto R = [&](int k) {
+      if (k + 2 < nk) issue(k + 2, SP, PG);
+      if (WORK) {
+        const char* base = smem + (k % 3) * BUF_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int r = row0 + 16 * i + fr;
+            af[s][i] = *(const half8_t*)(base + r * 128 + (((4 * s + fg) ^ ((r >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int r = col0 + 16 * j + fr;
+            bf[s][j] = *(const half8_t*)(base + (BM + r) * 128 + (((4 * s + fg) ^ ((r >> 1) & 7)) << 4));
+          }
+        }
+      }
+    };
+    auto Mph = [&](int k) {
+      if (WORK) {
+        constexpr int TOT = 2 * MI * NJ, EVERY = SP > 0 ? TOT / (SP + 1) : TOT + 1;
+        int cnt = 0, ip = 0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+              ++cnt;
+              if (SP > 0 && cnt % EVERY == 0 && ip < SP) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 2 < nk) issue(k + 2, ip, ip + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                ++ip;
+              }
+            }
+      } else if (SP > 0) {
+        if (k + 2 < nk) issue(k + 2, 0, SP);
+      }
+    };
+    // prologue: stages 0 and 1 (every wave: all of its pieces)
+    issue(0, 0, PG);
+    if (nk > 1) issue(1, 0, PG);
+    if (nk > 1) wait_vm<PG>(); else wait_vm<0>();
+    barrier();
+    if (G == 1) barrier();  // group 1 starts one phase late
+    for (int k = 0; k < nk; ++k) {
+      R(k);
+      if (G == 1) {  // end of phase 2k+1: stage k+1 (read by group 0 in the next phase) has landed; the R part of stage k+2 may fly
+        if (k + 2 < nk) wait_vm<PG - SP>(); else wait_vm<0>();
+      }
+      barrier();
+      Mph(k);
+      if (G == 0) {  // end of phase 2k+1: the same wait for this group's pieces of stage k+1; all of stage k+2 may fly
+        if (k + 2 < nk) wait_vm<PG>(); else wait_vm<0>();
+        barrier();
+      } else if (k + 1 < nk) {
+        barrier();
+      }
+    }
+  };
+  if (grp == 0) body(std::integral_constant<int, 0>{});
+  else body(std::integral_constant<int, 1>{});
+  if (sink) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) t += acc[i][j];
+    if (t[0] + t[1] + t[2] + t[3] == 12345.678f) sink[threadIdx.x] = t[0];
+  }
+}
+
+template <int BM, int BN, int WORK, int SPLIT>
+static float run_pingpong(const half_t* A, const half_t* W, long M, long N, long K, float* sink, int reps) {
+  constexpr int lds = 3 * (BM + BN) * 128;
+  auto fn = k_pingpong<BM, BN, WORK, SPLIT>;
+  hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  std::vector<float> t;
+  for (int r = 0; r < reps + 1; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(fn, dim3(tm * tn), dim3(512), lds, 0, A, W, M, N, K, tm, tn, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (r) t.push_back(ms * 1e3f);
+  }
+  std::sort(t.begin(), t.end());
+  return t[t.size() / 2];
+}
+
+template <int BM, int BN>
+static void sweep_pingpong(const char* name, const half_t* A, const half_t* W, long M, long N, long K, float* sink) {
+  need(M, N, K);
+  const long tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  const double dma = (double)tm * tn * (BM + BN) * 2.0 * K, flops = 2.0 * M * N * K;
+  printf("%s  M=%ld N=%ld K=%ld tile %dx%d, 8 waves ping-pong, 3 stages (%ld tiles = %.2f rounds of 256, %.2f GB through LDS-DMA)\n", name,
+         M, N, K, BM, BN, tm * tn, tm * tn / 256.0, dma / 1e9);
+  auto line = [&](const char* what, float us, bool fl) {
+    printf("   %-46s %8.1f us  %5.1f B/clk/CU", what, us, dma / (us * 1e-6) / 256.0 / 2.4e9);
+    if (fl) printf("  %6.0f TFLOP/s", flops / (us * 1e-6) / 1e12);
+    printf("\n");
+  };
+  line("DMA only, all pieces in the R phase", run_pingpong<BM, BN, 0, 0>(A, W, M, N, K, sink, 5), false);
+  line("reads+MFMA + DMA, all pieces in the R phase", run_pingpong<BM, BN, 1, 0>(A, W, M, N, K, sink, 5), true);
+  line("reads+MFMA + DMA, 2 pieces in the M phase", run_pingpong<BM, BN, 1, 2>(A, W, M, N, K, sink, 5), true);
+  line("reads+MFMA + DMA, 3 pieces in the M phase", run_pingpong<BM, BN, 1, 3>(A, W, M, N, K, sink, 5), true);
+  line("reads+MFMA + DMA, all pieces in the M phase", run_pingpong<BM, BN, 1, 8>(A, W, M, N, K, sink, 5), true);
+}
+
 int main() {
   setvbuf(stdout, nullptr, _IOLBF, 0);
   const long Kmax = 5120;
@@ -384,6 +567,7 @@ int main() {
     for (long off = 0; off < 10240 * Kmax; off += (long)h.size())
       hipMemcpy(W + off, h.data(), std::min<long>(h.size(), 10240 * Kmax - off) * 2, hipMemcpyHostToDevice);
   }
+  if (getenv("RING_FULL")) {
   sweep<160, 160, 4>("ds2 ff2 +res    ", A, W, 54432, 640, 2560, sink);
   sweep_adirect("ds2 ff2 +res    ", A, W, 54432, 640, 2560, sink);
   sweep_adirect("ds2 attn_out    ", A, W, 54432, 640, 640, sink);
@@ -397,5 +581,20 @@ int main() {
   sweep<256, 128, 8>("ds2 ff2 8 waves ", A, W, 54432, 640, 2560, sink);
   sweep<256, 128, 8>("ds4 ff2 8 waves ", A, W, 13608, 1280, 5120, sink);
   sweep<192, 192, 8>("ds4 ff2 8w 192  ", A, W, 13608, 1280, 5120, sink);
+  }
+  sweep<160, 160, 4>("ds4 ff2         ", A, W, 13608, 1280, 5120, sink);
+  sweep_pingpong<192, 192>("ds4 ff2         ", A, W, 13608, 1280, 5120, sink);
+  sweep_pingpong<192, 160>("ds4 ff2         ", A, W, 13608, 1280, 5120, sink);
+  sweep_pingpong<256, 160>("ds4 ff2         ", A, W, 13608, 1280, 5120, sink);
+  sweep<160, 160, 4>("ds2 ff2 +res    ", A, W, 54432, 640, 2560, sink);
+  sweep_pingpong<192, 160>("ds2 ff2 +res    ", A, W, 54432, 640, 2560, sink);
+  sweep_pingpong<256, 160>("ds2 ff2 +res    ", A, W, 54432, 640, 2560, sink);
+  sweep_pingpong<192, 160>("ds2 attn_out    ", A, W, 54432, 640, 640, sink);
+  sweep_pingpong<192, 160>("ds1 ff2         ", A, W, 217728, 320, 1280, sink);
+  sweep_pingpong<256, 160>("ds1 ff2         ", A, W, 217728, 320, 1280, sink);
+  sweep<160, 160, 4>("ds2 geglu-like  ", A, W, 54432, 5120, 640, sink);
+  sweep_pingpong<192, 160>("ds2 geglu-like  ", A, W, 54432, 5120, 640, sink);
+  sweep_pingpong<256, 160>("ds2 geglu-like  ", A, W, 54432, 5120, 640, sink);
+  sweep_pingpong<192, 160>("ds2 conv-like   ", A, W, 54432, 640, 5760, sink);
   return 0;
 }
