@@ -162,6 +162,13 @@ typedef struct seva_attn_desc {
   /* non-zero: q already holds q * scale * log2(e) (see seva_gemm_desc.col_scale); `scale` is ignored
    * and the kernel evaluates softmax as exp2(q' . k - max) */
   int32_t q_prescaled;
+  /* optional workspace (ABI 7) for the K/V split of LONG sequences: with it, launches whose key length is >= 6144 (the joint
+   * view x space attention at 36x36 / 18x18: L = 27216 / 6804) run every query block as TWO workgroups over the two halves of
+   * the K/V tiles plus a small fp32 combine -- the split is a function of lk only, so a sample's result does not depend on
+   * the batch.  It fills the last, partly empty round of workgroup slots (2140 workgroups = 4.18 rounds of the 512 slots ->
+   * 8.36 half-length rounds).  Needs 2 * nb0 * nb1 * heads * lq * 66 floats; NULL = never split. */
+  float* split_ws;
+  int64_t split_ws_bytes;
 } seva_attn_desc;
 int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream);
 
@@ -203,6 +210,13 @@ typedef struct seva_groupnorm_desc {
    * belongs to one sample and a sample's statistics stay bitwise independent of the batch). */
   const float* stats1;
   const float* stats2;
+  /* split-precision outputs (ABI 7).  Non-zero: the output has pixel pitch 2 * (c1 + c2); channels [0, C) hold hi = f16(v) as
+   * usual and channels [C, 2C) lo = f16(v - f32(hi)).  A consumer GEMM / conv whose weights are duplicated over the two
+   * halves then sees the operand to ~22 bits (fp32 accumulation of hi * w + lo * w).  Used for the three operand roundings
+   * that dominate the network's error (tests/test_f16_floor_cpu.py): the head conv's input (split_out_f16) and the 1x1 skip
+   * convs' input (split_raw_f16).  Plain (non-modulated) and 6-component-modulated GroupNorms only. */
+  int32_t split_out_f16;
+  int32_t split_raw_f16;
 } seva_groupnorm_desc;
 int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t stream);
 
@@ -231,6 +245,12 @@ int seva_softmax_rows_f16(const float* x, int64_t ldx, void* out_f16, int64_t ld
 int seva_nchw_to_nhwc_f16(const float* x1, int32_t c1, const float* x2, int32_t c2,
                           const float* scale, void* out_f16, int32_t n, int32_t hw, int32_t cpad,
                           seva_stream_t stream);
+/* Same, split precision (ABI 7): channels [C, 2C), C = c1 + c2, receive lo = f16(v - f32(f16(v))) of the value whose f16(v)
+ * sits in [0, C); cpad >= 2C.  The stem conv (model.py:103) has 11 real channels in one 64-channel K-tile, so with its weights
+ * duplicated over [C, 2C) the network input enters at ~22 bits for free. */
+int seva_nchw_to_nhwc_f16_split(const float* x1, int32_t c1, const float* x2, int32_t c2,
+                                const float* scale, void* out_f16, int32_t n, int32_t hw, int32_t cpad,
+                                seva_stream_t stream);
 /* [rows][ld] f32 channels-last -> [n][c][hw] f32 (first c channels). */
 int seva_nhwc_to_nchw_f32(const float* x, int64_t ld, float* out, int32_t n, int32_t c,
                           int32_t hw, seva_stream_t stream);

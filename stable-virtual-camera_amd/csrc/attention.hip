@@ -34,6 +34,11 @@ struct AttnArgs {
   int32_t nb1, heads, lq, lk, qblocks;
   float scale_log2;  // softmax scale * log2(e)  (unused when q is pre-scaled)
   int32_t dbg;       // ablation bits (SEVA_ATTN_DBG; timing only): 1 no K/V reloads, 2 no softmax, 4 no P*V, 8 no Q*K
+  // K/V split (attn2_kernel<.., true> + attn_combine_kernel): every (batch, head, query block) is computed by `nsplit` workgroups,
+  // each over a contiguous range of whole K/V tiles, which leave their UN-normalised fp32 O rows and (m, l) in the workspace
+  float* part_o;     // [nsplit][batch * heads * lq][64]
+  float* part_ml;    // [nsplit][batch * heads * lq][2]
+  int32_t nsplit;
 };
 
 typedef short short8_t __attribute__((ext_vector_type(8)));
@@ -418,9 +423,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_kernel(AttnArgs p) {
 // the pipelined kernel).  Same LDS ring, operand layouts, online-softmax arithmetic and rounding as
 // attn_kernel<4, 64, true, false, true>; one loop body with a run-time buffer index, running source pointers, half-wave maximum
 // by v_permlane32_swap (as there).
-template <int KT>
+template <int KT, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   constexpr int NW = 4, QB = 2, KB = KT / 32;
+  // SPLIT: this workgroup walks only the K/V tiles [ksp * tps, (ksp + 1) * tps) of its (batch, head) and writes a partial result.
+  // Workgroups of one (batch, head, split) are adjacent in the launch order (they stream the same K/V range through one L2).
   __shared__ __attribute__((aligned(16))) char smem[3 * 2 * KT * 128];
   constexpr int BUF_BYTES = 2 * KT * 128;
   constexpr int IP = KT / 8 / NW;
@@ -438,13 +445,26 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   }
   const int qb = bid % p.qblocks;
   bid /= p.qblocks;
+  int ksp = 0;
+  if (SPLIT) {
+    ksp = bid % p.nsplit;
+    bid /= p.nsplit;
+  }
   const int head = bid % p.heads;
   const int batch = bid / p.heads;
   const int b0 = batch / p.nb1, b1 = batch - b0 * p.nb1;
+  // this workgroup's key range [key0, key0 + lk): the whole sequence, or the split's run of whole tiles
+  int key0 = 0, lk = p.lk;
+  if (SPLIT) {
+    const int nt_all = (p.lk + KT - 1) / KT, tps = (nt_all + p.nsplit - 1) / p.nsplit;
+    key0 = ksp * tps * KT;
+    const int key1 = (ksp + 1) * tps * KT < p.lk ? (ksp + 1) * tps * KT : p.lk;
+    lk = key1 - key0;  // > 0: the host only splits when every split gets at least one tile
+  }
 
   const half_t* const qbase = p.q + b0 * p.q_sb0 + b1 * p.q_sb1 + head * 64;
-  const half_t* const kbase = p.k + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
-  const half_t* const vbase = p.v + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
+  const half_t* const kbase = p.k + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64 + (int64_t)key0 * p.k_sl;
+  const half_t* const vbase = p.v + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64 + (int64_t)key0 * p.k_sl;
   half_t* const obase = p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64;
 
   half8_t qf[QB][4];
@@ -473,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   }
   constexpr float RESCALE_THR = 8.0f;
 
-  const int nt = (p.lk + KT - 1) / KT;
+  const int nt = (lk + KT - 1) / KT;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned smem_base =
       __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
@@ -483,12 +503,12 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
   for (int i = 0; i < IP; ++i) {
     const int row = 8 * (wave_u * IP + i) + sr;
-    const int key = row < p.lk ? row : p.lk - 1;
+    const int key = row < lk ? row : lk - 1;
     kp[i] = kbase + (int64_t)key * p.k_sl + k_chunk_swz(row, sp) * 8;
     vp[i] = vbase + (int64_t)key * p.k_sl + v_chunk_swz(row, sp) * 8;
   }
   const int64_t tile_stride = (int64_t)KT * p.k_sl;
-  const bool ragged = (p.lk % KT) != 0;
+  const bool ragged = (lk % KT) != 0;
   auto issue_tile = [&](int kt, int buf) {  // tiles are issued strictly in order 0, 1, 2, ...
     const bool clamp = ragged && kt == nt - 1 && kt > 0;
 #pragma unroll
@@ -497,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
       if (clamp) {
         const int row = 8 * (wave_u * IP + i) + sr;
         int key = kt * KT + row;
-        if (key >= p.lk) key = p.lk - 1;
+        if (key >= lk) key = lk - 1;
         const int64_t roff = (int64_t)key * p.k_sl;
         glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
         glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
@@ -555,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (key >= p.lk) sc[c][kb][r] = -1e30f;
+            if (key >= lk) sc[c][kb][r] = -1e30f;
           }
       }
       float mk[KB];
@@ -638,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[c][s]));  // retire the Q loads (see attn_kernel)
   __syncthreads();
-  const int nfull = p.lk / KT;
+  const int nfull = lk / KT;
   int buf = 0;
   for (int kt = 0; kt < nfull; ++kt) {
     tile(buf, std::false_type{}, kt);
@@ -646,6 +666,31 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   }
   if (nfull < nt) tile(buf, std::true_type{}, nfull);
 
+  if constexpr (SPLIT) {
+    // partial result: un-normalised O (relative to m_run) as fp32, 16 bytes per lane and (db, t), and (m_run, l) per query row
+    const int64_t rows_all = (int64_t)gridDim.x / (p.qblocks * p.nsplit) * p.lq;  // batch * heads * lq
+    const int64_t row_bh = ((int64_t)batch * p.heads + head) * p.lq;
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+      const int qrow = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c + qi;
+      const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
+      if (qrow < p.lq) {
+        float* const po = p.part_o + ((int64_t)ksp * rows_all + row_bh + qrow) * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            *(f32x4*)(po + 32 * db + 8 * t + 4 * hh) =
+                f32x4{acc_o[c][db][4 * t], acc_o[c][db][4 * t + 1], acc_o[c][db][4 * t + 2], acc_o[c][db][4 * t + 3]};
+        if (hh == 0) {
+          float* const pm = p.part_ml + ((int64_t)ksp * rows_all + row_bh + qrow) * 2;
+          pm[0] = m_run[c];
+          pm[1] = l_tot;
+        }
+      }
+    }
+    return;
+  }
   __syncthreads();  // every wave is done reading K/V tiles
 #pragma unroll
   for (int c = 0; c < QB; ++c) {
@@ -678,6 +723,49 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
       if (q0 + row < p.lq) *(uint4*)(obase + (int64_t)(q0 + row) * p.o_sl + lchunk * 8) = v;
     }
   }
+}
+
+// Combine of the K/V-split partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i, one thread per (row, 8 columns).
+// Fixed order over the splits, exp2 of exact differences: deterministic, and (the split being a function of the sequence
+// lengths only) independent of what else is in the batch.
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p, int64_t rows_all) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows_all * 8) return;
+  const int64_t row = i >> 3;
+  const int ch = (int)(i & 7);
+  float m[4], l[4], mx = -3.0e38f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < p.nsplit) {
+      const float* pm = p.part_ml + ((int64_t)s * rows_all + row) * 2;
+      m[s] = pm[0];
+      l[s] = pm[1];
+      mx = fmaxf(mx, m[s]);
+    }
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lt = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < p.nsplit) {
+      const float w = __builtin_amdgcn_exp2f(m[s] - mx);
+      lt += w * l[s];
+      const float* po = p.part_o + ((int64_t)s * rows_all + row) * 64 + 8 * ch;
+      const f32x4 a = *(const f32x4*)po, b = *(const f32x4*)(po + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] += w * a[r];
+        o[4 + r] += w * b[r];
+      }
+    }
+  const float inv = 1.0f / lt;
+  half8_t h;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) h[r] = (half_t)(o[r] * inv);
+  // row = (batch * heads + head) * lq + q
+  const int64_t q = row % p.lq, bh = row / p.lq;
+  const int head = (int)(bh % p.heads);
+  const int64_t batch = bh / p.heads;
+  const int64_t b0 = batch / p.nb1, b1 = batch - b0 * p.nb1;
+  *(half8_t*)(p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64 + q * p.o_sl + 8 * ch) = h;
 }
 
 #ifdef SEVA_EXPERIMENTAL  // experimental library only (make exp; knob attn_two = 3): measured +1 %, not shipped in libseva_hip.so
@@ -1085,6 +1173,27 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
     if (nb <= 0 || nb > 0x7fffffff) {
       seva_set_error("attention: bad grid %lld", (long long)nb);
       return SEVA_ERR_ARG;
+    }
+    // K/V split (seva_attn_desc.split_ws): two workgroups per query block for long key sequences.  The factor is a function of
+    // lk alone (never of the batch); knob attn_split: 0 = never, 2..4 = that factor wherever a workspace is given.
+    int nsplit = d->lk >= 6144 ? 2 : 1;
+    if (g_seva_knobs.attn_split >= 0) nsplit = g_seva_knobs.attn_split > 4 ? 4 : g_seva_knobs.attn_split;
+    const int nt_all = (d->lk + 63) / 64;
+    while (nsplit >= 2 && (nt_all + nsplit - 1) / nsplit * (nsplit - 1) >= nt_all) --nsplit;  // every split gets >= 1 tile
+    if (nsplit >= 2 && d->split_ws != nullptr) {
+      const int64_t rows_all = batch * a.heads * (int64_t)a.lq;
+      SEVA_REQUIRE(d->split_ws_bytes >= nsplit * rows_all * 66 * 4 && (uintptr_t)d->split_ws % 16 == 0,
+                   "attention: split_ws too small (%lld bytes, need %lld) or misaligned", (long long)d->split_ws_bytes,
+                   (long long)(nsplit * rows_all * 66 * 4));
+      SEVA_REQUIRE(nb * nsplit <= 0x7fffffff && rows_all * 8 / 256 + 1 <= 0x7fffffff, "attention: split grid too large");
+      args.nsplit = nsplit;
+      args.part_o = d->split_ws;
+      args.part_ml = d->split_ws + (int64_t)nsplit * rows_all * 64;
+      hipLaunchKernelGGL((attn2_kernel<64, true>), dim3((unsigned)(nb * nsplit)), dim3(256), 0, s, args);
+      int rc = seva_check_launch("attn2_kernel<split>");
+      if (rc) return rc;
+      hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((rows_all * 8 + 255) / 256)), dim3(256), 0, s, args, rows_all);
+      return seva_check_launch("attn_combine_kernel");
     }
     hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
     return seva_check_launch("attn2_kernel");

@@ -37,6 +37,7 @@ const KnobEntry kKnobs[] = {
     {"gemm_bm", "SEVA_GEMM_BM", &SevaKnobs::gemm_bm}, {"gemm_bn", "SEVA_GEMM_BN", &SevaKnobs::gemm_bn},
     {"gemm_astat", "SEVA_GEMM_ASTAT", &SevaKnobs::gemm_astat}, {"attn_dbg", "SEVA_ATTN_DBG", &SevaKnobs::attn_dbg},
     {"attn_no_tr", "SEVA_ATTN_NO_TR", &SevaKnobs::attn_no_tr}, {"attn_two", "SEVA_ATTN_TWO", &SevaKnobs::attn_two},
+    {"attn_split", "SEVA_ATTN_SPLIT", &SevaKnobs::attn_split},
     {"gn_min_iter", "SEVA_GN_MIN_ITER", &SevaKnobs::gn_min_iter}, {"ff_variant", "SEVA_FF_VARIANT", &SevaKnobs::ff_variant},
 };
 SevaKnobs knobs_from_env() {
@@ -87,7 +88,7 @@ SevaProfScope::~SevaProfScope() {
 extern "C" {
 
 const char* seva_last_error(void) { return g_err; }
-int seva_abi_version(void) { return 6; }
+int seva_abi_version(void) { return 7; }
 const char* seva_target_arch(void) { return "gfx950"; }
 
 int seva_set_knob(const char* name, int value) {

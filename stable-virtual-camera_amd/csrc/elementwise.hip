@@ -14,10 +14,13 @@ inline unsigned grid_for(int64_t work, int per_block = EW_THREADS, int64_t cap =
 }
 
 // [n][c][hw] (two sources) -> [n][hw][cpad] f16; one thread per pixel writes whole 16-byte chunks
+// split != 0: channels [C, 2C) (C = c1 + c2) receive the LOW part of the same value, lo = f16(v - f32(f16(v))): with the conv
+// weights duplicated over those channels the fp32-accumulating MFMA sees the operand to ~22 bits at no extra K-tile
+// (the stem has 11 real channels in a 64-channel K-tile).
 __global__ void nchw_to_nhwc_f16_kernel(const float* __restrict__ x1, int c1,
                                         const float* __restrict__ x2, int c2,
                                         const float* __restrict__ scale, half_t* __restrict__ out,
-                                        int n, int hw, int cpad) {
+                                        int n, int hw, int cpad, int split) {
   const int64_t total = (int64_t)n * hw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -28,11 +31,13 @@ __global__ void nchw_to_nhwc_f16_kernel(const float* __restrict__ x1, int c1,
       half8_t h;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int c = c0 + r;
+        const int C = c1 + c2;
+        const bool lo = split && c0 + r >= C && c0 + r < 2 * C;
+        const int c = lo ? c0 + r - C : c0 + r;
         float v = 0.f;
         if (c < c1) v = x1[((int64_t)img * c1 + c) * hw + pix] * sc;
-        else if (c < c1 + c2) v = x2[((int64_t)img * c2 + (c - c1)) * hw + pix];
-        h[r] = (half_t)v;
+        else if (c < C) v = x2[((int64_t)img * c2 + (c - c1)) * hw + pix];
+        h[r] = lo ? (half_t)(v - (float)(half_t)v) : (half_t)v;
       }
       *(half8_t*)(o + c0) = h;
     }
@@ -277,7 +282,18 @@ extern "C" int seva_nchw_to_nhwc_f16(const float* x1, int32_t c1, const float* x
   SEVA_REQUIRE(cpad % 8 == 0 && cpad >= c1 + c2, "nchw_to_nhwc: cpad=%d (c=%d)", cpad, c1 + c2);
   SevaProfScope prof(4, (double)n * hw * ((c1 + c2) * 4.0 + cpad * 2.0), (hipStream_t)stream);
   EW_LAUNCH(nchw_to_nhwc_f16_kernel, (int64_t)n * hw, x1, c1, x2, c2, scale, (half_t*)out_f16, n,
-            hw, cpad);
+            hw, cpad, 0);
+}
+
+extern "C" int seva_nchw_to_nhwc_f16_split(const float* x1, int32_t c1, const float* x2, int32_t c2,
+                                           const float* scale, void* out_f16, int32_t n, int32_t hw,
+                                           int32_t cpad, seva_stream_t stream) {
+  SEVA_REQUIRE(x1 && out_f16 && n > 0 && hw > 0 && c1 > 0, "nchw_to_nhwc_split: bad args");
+  SEVA_REQUIRE(c2 == 0 || x2, "nchw_to_nhwc_split: c2 > 0 needs x2");
+  SEVA_REQUIRE(cpad % 8 == 0 && cpad >= 2 * (c1 + c2), "nchw_to_nhwc_split: cpad=%d must hold 2 x %d channels", cpad, c1 + c2);
+  SevaProfScope prof(4, (double)n * hw * ((c1 + c2) * 4.0 + cpad * 2.0), (hipStream_t)stream);
+  EW_LAUNCH(nchw_to_nhwc_f16_kernel, (int64_t)n * hw, x1, c1, x2, c2, scale, (half_t*)out_f16, n,
+            hw, cpad, 1);
 }
 
 extern "C" int seva_nhwc_to_nchw_f32(const float* x, int64_t ld, float* out, int32_t n, int32_t c,

@@ -30,6 +30,9 @@ struct GnArgs {
   uint8_t* out8;    // optional: e4m3 output (A operand of an fp8 GEMM / conv), pixel pitch ld8 (>= C; pad bytes untouched)
   int64_t ld8;
   half_t* raw_out;  // optional: plain f16 copy of the (concatenated) input, same layout as out
+  // split-precision outputs (SPLIT instantiations): pixel pitch 2C, channels [C, 2C) hold lo = f16(v - f32(f16(v))) of the value
+  // whose high part f16(v) sits in [0, C).  The consumer GEMM / conv duplicates its weights over the two halves.
+  int32_t split_out, split_raw;
   float* ws;
   const float* stats1;  // optional: per-channel 64-row-block partial statistics of x1 / x2 from the producing GEMM epilogue
   const float* stats2;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void gn_finalize_ch_kernel(GnArgs p) {
 
 // DC6: the modulation has exactly 6 components (the Pluecker maps -- every modulated GroupNorm of the network): weight pairs and
 // loops are sized for 6 at compile time (48 instead of 64 registers of weights, 6 instead of 8 packed FMAs per channel)
-template <bool DENSE, bool DC6 = false>
+template <bool DENSE, bool DC6 = false, bool SPLIT = false>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
   constexpr int ND = DC6 ? 6 : GN_MAX_DENSE;
   __shared__ float g_mean[GN_MAX_GROUPS], g_rstd[GN_MAX_GROUPS];
@@ -284,11 +287,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
           y4[r] = y;
         }
         if (pix < p_end) {
-          if (p.out) *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * C + c0) = h;
+          const int64_t ldo = (SPLIT && p.split_out) ? 2 * C : C, ldr = (SPLIT && p.split_raw) ? 2 * C : C;
+          if (p.out) {
+            *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * ldo + c0) = h;
+            if (SPLIT && p.split_out) {
+              const half4_t l = {(half_t)(y4[0] - (float)h[0]), (half_t)(y4[1] - (float)h[1]), (half_t)(y4[2] - (float)h[2]),
+                                 (half_t)(y4[3] - (float)h[3])};
+              *(half4_t*)(p.out + ((int64_t)n * p.hw + pix) * ldo + C + c0) = l;
+            }
+          }
           if (p.out8) *(int*)(p.out8 + ((int64_t)n * p.hw + pix) * p.ld8 + c0) = pack_fp8x4(y4[0], y4[1], y4[2], y4[3]);
           if (p.raw_out) {  // the un-normalised input as f16: A operand of the ResBlock's 1x1 skip conv
             const half4_t hr = {(half_t)v[u][0], (half_t)v[u][1], (half_t)v[u][2], (half_t)v[u][3]};
-            *(half4_t*)(p.raw_out + ((int64_t)n * p.hw + pix) * C + c0) = hr;
+            *(half4_t*)(p.raw_out + ((int64_t)n * p.hw + pix) * ldr + c0) = hr;
+            if (SPLIT && p.split_raw) {
+              const half4_t lr = {(half_t)(v[u][0] - (float)hr[0]), (half_t)(v[u][1] - (float)hr[1]), (half_t)(v[u][2] - (float)hr[2]),
+                                  (half_t)(v[u][3] - (float)hr[3])};
+              *(half4_t*)(p.raw_out + ((int64_t)n * p.hw + pix) * ldr + C + c0) = lr;
+            }
           }
         }
       }
@@ -439,6 +455,8 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
   a.n = d->n; a.hw = d->hw; a.c1 = d->c1; a.c2 = d->c2; a.groups = d->groups;
   a.dense_c = d->dense_c; a.silu = d->silu; a.eps = d->eps;
   a.stats1 = d->stats1; a.stats2 = d->stats2;
+  a.split_out = d->split_out_f16 != 0; a.split_raw = d->split_raw_f16 != 0;
+  SEVA_REQUIRE((!a.split_out || d->out_f16) && (!a.split_raw || d->raw_f16), "groupnorm: split_* needs the output it splits");
   SEVA_REQUIRE(!d->stats2 || d->stats1, "groupnorm: stats2 without stats1");
   if (d->stats1) {
     SEVA_REQUIRE(d->hw % 64 == 0, "groupnorm: producer statistics need hw %% 64 == 0 (hw=%d)", d->hw);
@@ -489,7 +507,15 @@ extern "C" int seva_groupnorm_f16(const seva_groupnorm_desc* d, seva_stream_t st
     rc = seva_check_launch("gn_finalize_kernel");
     if (rc) return rc;
   }
-  if (d->dense && d->dense_c == 6)
+  const bool split = a.split_out || a.split_raw;  // split-precision outputs: their own instantiations (the hot ones stay as they are)
+  if (split && d->dense && d->dense_c == 6)
+    hipLaunchKernelGGL((gn_apply_kernel<true, true, true>), dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
+  else if (split && !d->dense)
+    hipLaunchKernelGGL((gn_apply_kernel<false, false, true>), dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
+  else if (split) {
+    seva_set_error("groupnorm: split-precision outputs with a %d-component modulation are not instantiated", d->dense_c);
+    return SEVA_ERR_ARG;
+  } else if (d->dense && d->dense_c == 6)
     hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);
   else if (d->dense)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nslab_apply, d->n, zchunks), dim3(apply_threads), 0, s, a);

@@ -33,7 +33,7 @@ int seva_check_launch(const char* what);
 // getenv on the launch path); tests and tools change them at run time through seva_set_knob().  -1 = unset.
 struct SevaKnobs {
   int gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat, gemm_streamk;
-  int attn_dbg, attn_no_tr, attn_two;
+  int attn_dbg, attn_no_tr, attn_two, attn_split;
   int gn_min_iter;
   int ff_variant;
 };

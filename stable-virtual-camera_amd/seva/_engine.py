@@ -115,6 +115,12 @@ class SevaEngine:
         self.gn_fused_stats = int(_os.environ.get("SEVA_GN_FUSED_STATS", "1"))
         self._stats: dict = {}
         self.conv_splitk = _os.environ.get("SEVA_CONV_SPLITK", "1") != "0"  # 0: 64-row tiles at the 9x9 level (A/B runs)
+        self.attn_split = _os.environ.get("SEVA_ATTN_SPLIT_KV", "1") != "0"  # 0: joint attention never K/V-split (A/B runs)
+        # Split-precision operands (hi + lo f16 pairs against duplicated weights) for the three operand roundings that dominate the
+        # network's error budget (tests/test_f16_floor_cpu.py: 1x1 skip convs 4.9e-4, stem 2.4e-4, head 2.3e-4 of 8.1e-4):
+        # comma list of "stem", "head", "skip"; "" = every operand plain fp16 (the round-2 numerics).
+        sp = _os.environ.get("SEVA_SPLIT_PRECISION", "stem,head,skip")
+        self.split = {t for t in sp.split(",") if t} if not self.fp8 else set()
         self.p = model.params
         self.layout: Layout = model._layout
         self.arena = _Arena(self.device)
@@ -204,7 +210,10 @@ class SevaEngine:
         for spec in self.layout.all_specs():
             pfx = spec.prefix
             if spec.kind == "conv":
-                W[pfx + ".w"] = pack_conv3x3(f32(pfx + ".weight"), CIN_PAD * ((spec.cin + CIN_PAD - 1) // CIN_PAD))
+                wc = f32(pfx + ".weight")
+                if "stem" in self.split and 2 * spec.cin <= CIN_PAD:  # [w | w]: the input arrives as [hi | lo] channels
+                    wc = torch.cat([wc, wc], 1)
+                W[pfx + ".w"] = pack_conv3x3(wc, CIN_PAD * ((wc.shape[1] + CIN_PAD - 1) // CIN_PAD))
                 W[pfx + ".b"] = f32(pfx + ".bias")
             elif spec.kind == "res":
                 assert spec.cin % 64 == 0 and spec.cout % 64 == 0, "channel counts must be multiples of 64"
@@ -226,7 +235,9 @@ class SevaEngine:
                 self.emb_off[pfx] = emb_total
                 emb_total += spec.cout
                 if spec.cin != spec.cout:
-                    W[pfx + ".skip.w"] = f16(pfx + ".skip_connection.weight").reshape(spec.cout, spec.cin).contiguous()
+                    ws = f16(pfx + ".skip_connection.weight").reshape(spec.cout, spec.cin)
+                    # split precision: the raw input arrives as [hi | lo] (K = 2 cin), the weights are duplicated
+                    W[pfx + ".skip.w"] = (torch.cat([ws, ws], 1) if "skip" in self.split else ws).contiguous()
                     W[pfx + ".skip.b"] = f32(pfx + ".skip_connection.bias")
             elif spec.kind == "mvt":
                 pack_ln(pfx + ".norm")
@@ -251,7 +262,9 @@ class SevaEngine:
             elif spec.kind == "up":
                 W[pfx + ".w"], W[pfx + ".b"] = pack_conv3x3(f32(pfx + ".conv.weight")), f32(pfx + ".conv.bias")
         pack_ln("out.0")
-        W["out.2.w"], W["out.2.b"] = pack_conv3x3(f32("out.2.weight")), f32("out.2.bias")
+        wh = f32("out.2.weight")
+        W["out.2.w"] = pack_conv3x3(torch.cat([wh, wh], 1) if "head" in self.split else wh)  # head input [hi | lo] per tap
+        W["out.2.b"] = f32("out.2.bias")
         W["emb_all.w"], W["emb_all.b"] = torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous()
         W["ctx_all.w"], W["ctx_all.b"] = torch.cat(ctx_w, 0).contiguous(), torch.cat(ctx_b, 0).contiguous()
         self.emb_total, self.ctx_total = emb_total, ctx_total
@@ -366,11 +379,12 @@ class SevaEngine:
         cin8, cout8 = _pad128(cin), _pad128(cout)  # fp8 convs see channel counts padded to a multiple of 128 (pad stays zero)
         a8 = self._buf("gn8", (n, hw, cin8), U8, zero=True) if f8_1 else None
         # the 1x1 skip conv (cin != cout) consumes the raw input as f16: emitted by the same GroupNorm pass
-        xs16 = self._buf("skip16", (n * hw, cin), F16) if cin != cout else None
+        sp_skip = "skip" in self.split and cin != cout
+        xs16 = self._buf("skip16", (n * hw, (2 if sp_skip else 1) * cin), F16) if cin != cout else None
         s1, s2 = self._gn_stats(x1, x2)
         ops.groupnorm(x1, x2, W[pfx + ".in_layers.0.g"], W[pfx + ".in_layers.0.b"], a16, self.gn_ws,
                       eps=1e-5, silu=True, dense=dense, dense_w=W[pfx + ".dense.w"], dense_b=W[pfx + ".dense.b"],
-                      raw_f16=xs16, out_f8=a8, stats1=s1, stats2=s2)
+                      raw_f16=xs16, out_f8=a8, stats1=s1, stats2=s2, split_raw=sp_skip)
         hmid = self._buf("res_mid", (n, hw, cout), F32)
         st_mid = self._stats_buf("res_mid", n * hw, hw, cout)
         off = self.emb_off[pfx]
@@ -442,9 +456,13 @@ class SevaEngine:
                           q_strides=(hw * c3, 0, c3), k_strides=(hw * c3, 0, c3), o_strides=(hw * c, 0, c),
                           q_prescaled=True)
         elif regime == "joint":  # batch = scene, tokens = (frame, pixel)
+            # long key sequences (L = T hw >= 6144) run K/V-split: the workspace for the two partial results
+            sws = None
+            if self.attn_split and T * hw >= ops.ATTN_SPLIT_MIN_LK:
+                sws = self._buf("attn_split", (ops.attention_split_workspace_numel(n // T, heads, T * hw),), F32)
             ops.attention(q, k, v, att, nb0=n // T, nb1=1, heads=heads, lq=T * hw, lk=T * hw,
                           q_strides=(T * hw * c3, 0, c3), k_strides=(T * hw * c3, 0, c3),
-                          o_strides=(T * hw * c, 0, c), q_prescaled=True)
+                          o_strides=(T * hw * c, 0, c), q_prescaled=True, split_ws=sws)
         else:  # temporal: batch = (scene, pixel), tokens = frames, read through strides
             ops.attention(q, k, v, att, nb0=n // T, nb1=hw, heads=heads, lq=T, lk=T,
                           q_strides=(T * hw * c3, c3, hw * c3), k_strides=(T * hw * c3, c3, hw * c3),
@@ -677,9 +695,10 @@ class SevaEngine:
 
         # --- stem ---
         stem = lay.input_blocks[0][0]
-        cpad = CIN_PAD * ((cin + CIN_PAD - 1) // CIN_PAD)
+        sp_stem = "stem" in self.split and 2 * cin <= CIN_PAD
+        cpad = CIN_PAD * (((2 if sp_stem else 1) * cin + CIN_PAD - 1) // CIN_PAD)
         x16 = self._buf("x16", (n, h, w, cpad), F16)
-        ops.nchw_to_nhwc_f16(x, concat, x16)
+        ops.nchw_to_nhwc_f16(x, concat, x16, split=sp_stem)
         cur = self._buf("out:" + stem.prefix, (n, h * w, stem.cout), F32)
         st_stem = self._stats_buf("out:" + stem.prefix, n * h * w, h * w, stem.cout)
         ops.conv3x3(x16, W[stem.prefix + ".w"], bias=W[stem.prefix + ".b"], out_f32=cur, ch_stats=st_stem)
@@ -709,11 +728,13 @@ class SevaEngine:
 
         # --- head: GroupNorm + SiLU + conv3x3 (model.py:170-174) ---
         cfin = lay.final_channels
-        g16 = self._buf("gn16", (n, ch * cw, cfin), F16)
+        sp_head = "head" in self.split
+        cf2 = (2 if sp_head else 1) * cfin
+        g16 = self._buf("gn16", (n, ch * cw, cf2), F16)
         ops.groupnorm(cur, None, W["out.0.g"], W["out.0.b"], g16, self.gn_ws, eps=1e-5, silu=True,
-                      stats1=self._gn_stats(cur, None)[0])
+                      stats1=self._gn_stats(cur, None)[0], split_out=sp_head)
         o_nhwc = self._buf("head", (n, ch * cw, p.out_channels), F32)
-        ops.conv3x3(g16.view(n, ch, cw, cfin), W["out.2.w"], bias=W["out.2.b"], out_f32=o_nhwc)
+        ops.conv3x3(g16.view(n, ch, cw, cf2), W["out.2.w"], bias=W["out.2.b"], out_f32=o_nhwc)
         if out is None:
             out = torch.empty((n, p.out_channels, ch, cw), dtype=F32, device=self.device)
         ops.nhwc_to_nchw_f32(o_nhwc, out)

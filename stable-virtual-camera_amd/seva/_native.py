@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
 
@@ -59,6 +59,7 @@ class AttnDesc(C.Structure):
         ("o_sb0", c_int64), ("o_sb1", c_int64), ("o_sl", c_int64),
         ("nb0", c_int32), ("nb1", c_int32), ("heads", c_int32),
         ("lq", c_int32), ("lk", c_int32), ("scale", c_float), ("q_prescaled", c_int32),
+        ("split_ws", c_void_p), ("split_ws_bytes", c_int64),
     ]
 
 
@@ -71,6 +72,7 @@ class GroupNormDesc(C.Structure):
         ("groups", c_int32), ("dense_c", c_int32), ("silu", c_int32), ("eps", c_float),
         ("raw_f16", c_void_p), ("out_f8", c_void_p), ("ld_out_f8", c_int64),
         ("stats1", c_void_p), ("stats2", c_void_p),
+        ("split_out_f16", c_int32), ("split_raw_f16", c_int32),
     ]
 
 
@@ -93,6 +95,7 @@ SYMBOLS = {
                                          c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "seva_softmax_rows_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "seva_nchw_to_nhwc_f16": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "seva_nchw_to_nhwc_f16_split": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "seva_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "seva_cast_concat_f16": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "seva_bilinear_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -239,6 +239,7 @@ def attention(
     o_strides: tuple[int, int, int],
     scale: float = 0.125,
     q_prescaled: bool = False,
+    split_ws: torch.Tensor | None = None,
 ) -> None:
     """softmax(q k^T * scale) v per (batch, head), head dim 64 (seva_attention_f16).
     q_prescaled: q already holds q * scale * log2(e) (gemm(col_scale=...)); `scale` is then ignored.
@@ -253,7 +254,18 @@ def attention(
     d.o_sb0, d.o_sb1, d.o_sl = o_strides
     d.nb0, d.nb1, d.heads, d.lq, d.lk, d.scale = nb0, nb1, heads, lq, lk, scale
     d.q_prescaled = 1 if q_prescaled else 0
+    if split_ws is not None:  # `attention_split_workspace`: lets long key sequences run K/V-split (seva_attn_desc.split_ws)
+        assert split_ws.dtype == F32 and split_ws.is_contiguous()
+        d.split_ws, d.split_ws_bytes = split_ws.data_ptr(), split_ws.numel() * 4
     check(_lib().seva_attention_f16(C.byref(d), stream_ptr(q.device)), "seva_attention_f16")
+
+
+ATTN_SPLIT_MIN_LK = 6144  # key length from which seva_attention_f16 splits the K/V range in two (include/seva_hip.h)
+
+
+def attention_split_workspace_numel(batch: int, heads: int, lq: int, nsplit: int = 2) -> int:
+    """fp32 elements of `attention(split_ws=...)`: per split, 64 floats of un-normalised O plus (m, l) per query row."""
+    return nsplit * batch * heads * lq * 66
 
 
 GN_WORKSPACE_SLABS = 1024  # include/seva_hip.h SEVA_GN_WORKSPACE_SLABS
@@ -281,8 +293,11 @@ def groupnorm(
     out_f8: torch.Tensor | None = None,
     stats1: torch.Tensor | None = None,
     stats2: torch.Tensor | None = None,
+    split_out: bool = False,
+    split_raw: bool = False,
 ) -> None:
     """GroupNorm(+SiLU)(+Pluecker modulation) of cat(x1, x2) -> f16; x: [n, hw, c] f32.
+    split_out / split_raw: out_f16 / raw_f16 are [n, hw, 2c] and carry [hi | lo] (seva_groupnorm_desc.split_*).
     raw_f16: optional second output, cat(x1, x2) merely cast to f16 (same pass).
     out_f8: optional e4m3 output (uint8 tensor, same layout); out_f16 may then be None.
     stats1 / stats2: the `ch_stats` buffers the kernels that produced x1 / x2 filled (both or none; hw % 64 == 0): the
@@ -309,7 +324,10 @@ def groupnorm(
         d.stats1, d.stats2 = stats1.data_ptr(), ptr(stats2)
     else:
         assert stats2 is None
-    assert raw_f16 is None or (raw_f16.dtype == F16 and raw_f16.is_contiguous() and raw_f16.numel() == n * hw * (c1 + c2))
+    assert raw_f16 is None or (raw_f16.dtype == F16 and raw_f16.is_contiguous()
+                               and raw_f16.numel() == n * hw * (c1 + c2) * (2 if split_raw else 1))
+    assert not split_out or (out_f16 is not None and out_f16.is_contiguous() and out_f16.numel() == 2 * n * hw * (c1 + c2))
+    d.split_out_f16, d.split_raw_f16 = int(split_out), int(split_raw)
     assert workspace.numel() >= n * GN_WORKSPACE_SLABS * groups * 2
     check(_lib().seva_groupnorm_f16(C.byref(d), stream_ptr(x1.device)), "seva_groupnorm_f16")
 
@@ -396,14 +414,15 @@ def softmax_rows(x: torch.Tensor, out_f16: torch.Tensor, cols: int, scale: float
 
 
 def nchw_to_nhwc_f16(x1: torch.Tensor, x2: torch.Tensor | None, out_f16: torch.Tensor,
-                     scale: torch.Tensor | None = None) -> None:
+                     scale: torch.Tensor | None = None, split: bool = False) -> None:
+    """split: channels [C, 2C) of the output receive the low parts f16(v - f32(f16(v))) (seva_nchw_to_nhwc_f16_split)."""
     require_cuda(x1, out_f16)
     n, c1 = x1.shape[:2]
     hw = x1.numel() // (n * c1)
     c2 = x2.shape[1] if x2 is not None else 0
-    check(_lib().seva_nchw_to_nhwc_f16(x1.data_ptr(), c1, ptr(x2), c2, ptr(scale),
-                                       out_f16.data_ptr(), n, hw, out_f16.shape[-1],
-                                       stream_ptr(x1.device)), "seva_nchw_to_nhwc_f16")
+    fn = _lib().seva_nchw_to_nhwc_f16_split if split else _lib().seva_nchw_to_nhwc_f16
+    check(fn(x1.data_ptr(), c1, ptr(x2), c2, ptr(scale), out_f16.data_ptr(), n, hw, out_f16.shape[-1],
+             stream_ptr(x1.device)), "seva_nchw_to_nhwc_f16")
 
 
 def nhwc_to_nchw_f32(x: torch.Tensor, out: torch.Tensor) -> None:

@@ -145,8 +145,15 @@ def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per
               out_f16, False, ch_stats=ch_stats)
 
 
+ATTN_SPLIT_MIN_LK = 6144
+
+
+def attention_split_workspace_numel(batch, heads, lq, nsplit=2):
+    return nsplit * batch * heads * lq * 66
+
+
 def attention(q, k, v, out, *, nb0, nb1, heads, lq, lk, q_strides, k_strides, o_strides, scale=0.125,
-              q_prescaled=False):
+              q_prescaled=False, split_ws=None):
     if q_prescaled:  # q carries scale * log2(e): softmax base 2
         scale = math.log(2.0)
     def view(t, st, L):
@@ -165,10 +172,18 @@ def groupnorm_workspace(n, device):
 
 
 def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, silu=False,
-              dense=None, dense_w=None, dense_b=None, raw_f16=None, out_f8=None, stats1=None, stats2=None):
+              dense=None, dense_w=None, dense_b=None, raw_f16=None, out_f8=None, stats1=None, stats2=None,
+              split_out=False, split_raw=False):
+    def hilo(v):  # [hi | lo] channels of the split-precision outputs (seva_groupnorm_desc.split_*)
+        hi = v.half()
+        return torch.cat([hi, (v - hi.float()).half()], -1)
+
     x = torch.cat([x1, x2], -1) if x2 is not None else x1
     if raw_f16 is not None:
-        raw_f16.view(x.shape).copy_(x.half())
+        if split_raw:
+            raw_f16.view(x.shape[:-1] + (2 * x.shape[-1],)).copy_(hilo(x))
+        else:
+            raw_f16.view(x.shape).copy_(x.half())
     C = x.shape[-1]
     if stats1 is not None:
         # statistics come from the producers' epilogues (seva_groupnorm_desc.stats1 / stats2): USE them, so that a wrong or
@@ -195,7 +210,7 @@ def groupnorm(x1, x2, gamma, beta, out_f16, workspace, *, groups=32, eps=1e-5, s
         d = dense @ dense_w.T + dense_b
         y = y * (1 + d[..., :C]) + d[..., C:]
     if out_f16 is not None:
-        out_f16.copy_(y.half())
+        out_f16.copy_(hilo(y) if split_out else y.half())
     if out_f8 is not None:
         out_f8[..., : y.shape[-1]].copy_(to_fp8(y))
 
@@ -241,14 +256,17 @@ def softmax_rows(x, out_f16, cols, scale):
     out_f16[:, :cols] = torch.softmax(x[:, :cols] * scale, -1).half()
 
 
-def nchw_to_nhwc_f16(x1, x2, out_f16, scale=None):
+def nchw_to_nhwc_f16(x1, x2, out_f16, scale=None, split=False):
     n = x1.shape[0]
     a = x1 if scale is None else x1 * scale.view(-1, 1, 1, 1)
     x = torch.cat([a, x2], 1) if x2 is not None else a
     c = x.shape[1]
     o = out_f16.view(n, -1, out_f16.shape[-1])
     o.zero_()
-    o[..., :c] = x.reshape(n, c, -1).transpose(1, 2).half()
+    v = x.reshape(n, c, -1).transpose(1, 2)
+    o[..., :c] = v.half()
+    if split:
+        o[..., c:2 * c] = (v - v.half().float()).half()
 
 
 def nhwc_to_nchw_f32(x, out):

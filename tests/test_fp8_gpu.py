@@ -183,6 +183,59 @@ def test_fp8_network_accuracy_is_reported(dev):
     assert e16 < 1e-3 and 1e-3 < e8 < 0.2 and nq > 100
 
 
+def test_fp8_forward_at_the_headline_shape_vs_reference(dev):
+    """BASELINE config 5 at the shape the metric is quoted on: ONE 1.3B network call at T=21, 576x576 (latent 72x72, CFG batch
+    42) in fp8 mode against the REFERENCE's own output (tests/golden/g9_T21_forward.npz).  Reported: overall and worst-latent
+    rel-L2.  Bounded: fp8 is a separate accuracy class (3 mantissa bits per operand), asserted inside [1e-3, 6e-2] overall and
+    < 1e-1 per latent -- a wiring error (O(1)) fails, and so does a silent fall-back to f16 (< 1e-3)."""
+    import os
+    from conftest import GOLD, load_golden
+    from test_headline_gpu import FORWARD_SEEDS, HW, _wrapper_inputs
+    from test_model_gpu import _build
+    from seva.model import SGMWrapper
+    if not os.path.exists(os.path.join(GOLD, "g9_T21_forward.npz")):
+        pytest.skip("g9_T21_forward.npz not generated")
+    g = load_golden("g9_T21_forward")
+    T = 21
+    net, _ = _build("full", dev)
+    net.set_precision("fp8")
+    x, t, c = _wrapper_inputs(T, FORWARD_SEEDS[T])
+    y = SGMWrapper(net)(x.to(dev), t.to(dev), {k: v.to(dev) for k, v in c.items()}, num_frames=T).cpu()
+    ref = g["y"]
+    err = rel_l2(y, ref)
+    per = [rel_l2(y[i], ref[i]) for i in range(y.shape[0])]
+    nq = sum(1 for k in net.engine().W if k.endswith("8e"))
+    print(f"\nfp8 mode, 1.3B forward T=21 72x72 (B=42) vs REFERENCE: rel-L2 {err:.3e}; per latent max {max(per):.3e} min {min(per):.3e} "
+          f"({nq} e4m3 weight tensors; f16 mode: 8.1e-4)")
+    assert torch.isfinite(y).all() and 1e-3 < err < 6e-2 and max(per) < 1e-1 and nq > 100
+
+
+def test_fp8_activation_scale_is_not_the_error_lever(dev):
+    """Would a per-row (token) power-of-two activation scale -- carried as the activation operand's E8M0 block scale -- lower the
+    fp8 error?  e4m3 is a FLOATING-point format: a power-of-two scale moves the exponent window (normals 2^-6 .. 448), not the
+    3-bit mantissa, so it only matters for values outside that window.  Measured here on the tensors the fp8 GEMMs consume
+    (LayerNorm output, GroupNorm+SiLU output, GEGLU hidden activations of N(0,1)-scale inputs): the quantisation error with
+    the ideal per-row scale is within a few per cent of the unit-scale error, and both sit at the mantissa floor
+    (2^-4 / sqrt(3) ~ 3.6e-2 rms per element).  The unit activation scale of seva_gemm_fp8 stays."""
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4096, 1280, generator=g).to(dev)
+    tensors = {
+        "layernorm": F.layer_norm(x * 3 + 0.5, (1280,)) * (1 + 0.1 * torch.randn(1280, generator=g).to(dev)),
+        "groupnorm+silu": F.silu(F.group_norm((x * 2 + 1).view(4, 1024, 1280).permute(0, 2, 1), 32)).permute(0, 2, 1).reshape(4096, 1280),
+        "geglu hidden": (x[:, :640] * 1.5) * F.gelu(x[:, 640:] * 1.5),
+    }
+
+    def q(v):  # saturating e4m3 round trip
+        return v.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+    for name, a in tensors.items():
+        unit = rel_l2(q(a), a)
+        e = torch.ceil(torch.log2(a.abs().amax(1, keepdim=True).clamp_min(1e-30) / 448.0))
+        scaled = rel_l2(q(a * torch.exp2(-e)) * torch.exp2(e), a)
+        print(f"\ne4m3 quantisation error of {name}: unit scale {unit:.3e}, ideal per-row power-of-two scale {scaled:.3e}")
+        assert 1.5e-2 < scaled <= unit * 1.02 and unit < scaled * 1.25
+
+
 def test_fp8_reduction_padding_320_to_384(dev):
     """C = 320 level in fp8 mode: the reduction length is zero-padded to 384 (one more 128-deep MFMA K-tile instead of 2.5).
     LayerNorm writes its 320 columns into a zero-initialised [rows, 384] e4m3 buffer; GroupNorm writes 320 channels at pixel

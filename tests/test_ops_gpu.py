@@ -343,6 +343,50 @@ def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, knobs):
     assert rel_l2(out.cpu(), ref) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,L,Lk,split", [(2, 3, 6804, 6804, -1), (1, 2, 2300, 6150, -1), (2, 2, 2100, 700, 2), (1, 3, 2049, 1300, 3),
+                                            (3, 1, 2500, 257, 4), (1, 1, 2048, 129, 2)])
+def test_attention_kv_split(dev, B, H, L, Lk, split, knobs):
+    """K/V split of long key sequences (seva_attn_desc.split_ws: two workgroups per query block + an fp32 combine): against an
+    fp64 softmax reference, and against the unsplit kernel (same per-tile arithmetic, one extra fp32 re-association at the
+    combine).  Default rule (split -1): lk >= 6144 -> 2 halves; forced factors 2..4 cover uneven tile counts, a ragged last
+    tile in the last split and spikes that trigger the rescale branch in only one of the splits.  Without a workspace, or with
+    the knob at 0, nothing is split (bitwise the unsplit result)."""
+    from seva import ops
+    C = 64 * H
+    g = torch.Generator().manual_seed(313)
+    q = torch.randn((B, L, H, 64), generator=g)
+    k = torch.randn((B, Lk, H, 64), generator=g)
+    v = torch.randn((B, Lk, H, 64), generator=g)
+    k[:, Lk - 3] = 5.0 * q[:, L // 2]  # a late key (last split) that dominates one query row
+    k[:, 5] = 4.0 * q[:, 7]            # an early one (first split)
+    qs = (q * QK_C).half()
+    q16, k16, v16 = qs.to(dev).view(B, L, C), k.half().to(dev).view(B, Lk, C), v.half().to(dev).view(B, Lk, C)
+    ws = torch.empty(ops.attention_split_workspace_numel(B, H, L, 4), device=dev)
+
+    def run(knob, w):
+        knobs(attn_split=knob)
+        o = torch.full((B, L, C), float("nan"), device=dev, dtype=torch.float16)
+        ops.attention(q16, k16, v16, o, nb0=B, nb1=1, heads=H, lq=L, lk=Lk, q_strides=(L * C, 0, C), k_strides=(Lk * C, 0, C),
+                      o_strides=(L * C, 0, C), q_prescaled=True, split_ws=w)
+        torch.cuda.synchronize()
+        return o
+
+    plain = run(0, ws)
+    assert torch.equal(plain, run(split, None))  # no workspace -> never split
+    got = run(split, ws)
+    assert torch.isfinite(got).all()
+    qh = qs.double().transpose(1, 2).to(dev)
+    kh, vh = k.half().double().transpose(1, 2).to(dev), v.half().double().transpose(1, 2).to(dev)
+    ref = torch.empty((B, H, L, 64), dtype=torch.float64, device=dev)
+    for s0 in range(0, L, 1024):
+        ref[:, :, s0:s0 + 1024] = torch.softmax(qh[:, :, s0:s0 + 1024] @ kh.transpose(-1, -2) * math.log(2.0), -1) @ vh
+    ref = ref.transpose(1, 2).reshape(B, L, C)
+    e_split, e_plain, e_pair = rel_l2(got.double(), ref), rel_l2(plain.double(), ref), rel_l2(got.float(), plain.float())
+    print(f"\nK/V split B={B} H={H} L={L} Lk={Lk} factor {split}: vs fp64 {e_split:.2e} (unsplit {e_plain:.2e}), split vs unsplit {e_pair:.2e}")
+    assert e_split < 1e-3 and e_split < 1.2 * e_plain + 1e-5 and e_pair < 6e-4
+    assert not torch.equal(got, plain) or Lk < 128  # the split path really ran (a different association somewhere)
+
+
 @pytest.mark.parametrize("B,H,L,Lk", [(4, 5, 7000, 1100), (1, 10, 13500, 700), (3, 7, 6950, 640)])
 def test_attention_kernels_round_identically(dev, B, H, L, Lk, knobs):
     """attn_kernel (32 queries per wave) and the two-query-block kernel (64 per wave, shared K / V fragments) perform the same
@@ -482,6 +526,54 @@ def test_groupnorm_raw_f16_second_output(dev):
         ops.groupnorm(x1, x2, g, b, o1, ws, silu=True, raw_f16=raw, **kw)
         assert torch.equal(o0, o1)
         assert torch.equal(raw, torch.cat([x1, x2], -1).half())
+
+
+def test_split_precision_outputs_and_their_consumers(dev):
+    """Split-precision operands (seva_groupnorm_desc.split_*, seva_nchw_to_nhwc_f16_split): the [hi | lo] halves are exactly
+    hi = f16(v), lo = f16(v - f32(hi)); the hi half is bitwise the plain output; and a GEMM against duplicated weights [W | W]
+    reproduces the fp32 product to ~1e-6 where the plain f16 operand gives ~2e-4 (what the engine uses for the stem, the head
+    and the 1x1 skip convs: tests/test_f16_floor_cpu.py)."""
+    from seva import ops
+    n, hw, c1, c2 = 2, 192, 96, 32
+    C = c1 + c2
+    x1, x2 = _rand((n, hw, c1), dev, 61, 7.0), _rand((n, hw, c2), dev, 62, 7.0)
+    g, b = _rand((C,), dev, 63), _rand((C,), dev, 64)
+    dense, dw, db = _rand((n, hw, 6), dev, 65), _rand((2 * C, 6), dev, 66, 0.1), _rand((2 * C,), dev, 67, 0.1)
+    ws = ops.groupnorm_workspace(n, dev)
+    for kw in (dict(), dict(dense=dense, dense_w=dw, dense_b=db)):
+        o0, raw0 = torch.empty((n, hw, C), device=dev, dtype=torch.float16), torch.empty((n, hw, C), device=dev, dtype=torch.float16)
+        ops.groupnorm(x1, x2, g, b, o0, ws, silu=True, raw_f16=raw0, **kw)
+        # raw split (both variants); out split (plain variant only: the head GroupNorm is not modulated)
+        o1, raw1 = torch.empty_like(o0), torch.full((n, hw, 2 * C), float("nan"), device=dev, dtype=torch.float16)
+        ops.groupnorm(x1, x2, g, b, o1, ws, silu=True, raw_f16=raw1, split_raw=True, **kw)
+        x = torch.cat([x1, x2], -1)
+        assert torch.equal(o1, o0) and torch.equal(raw1[..., :C], raw0)
+        assert torch.equal(raw1[..., C:], (x - raw0.float()).half())
+    o2 = torch.full((n, hw, 2 * C), float("nan"), device=dev, dtype=torch.float16)
+    ops.groupnorm(x1, x2, g, b, o2, ws, silu=True, split_out=True)
+    o0 = torch.empty((n, hw, C), device=dev, dtype=torch.float16)
+    ops.groupnorm(x1, x2, g, b, o0, ws, silu=True)
+    y = F.silu(F.group_norm(torch.cat([x1, x2], -1).transpose(1, 2), 32, g, b, 1e-5)).transpose(1, 2)
+    assert torch.equal(o2[..., :C], o0)
+    assert rel_l2(o2[..., :C].float() + o2[..., C:].float(), y) < 2e-6 and rel_l2(o0, y) > 1e-4
+    # consumer: GEMM with duplicated weights
+    w = _rand((64, C), dev, 68, 0.2).half()
+    a_plain = raw0.view(n * hw, C)
+    a_split = raw1.view(n * hw, 2 * C)
+    out_p, out_s = torch.empty((n * hw, 64), device=dev), torch.empty((n * hw, 64), device=dev)
+    ops.gemm(a_plain, w, out_f32=out_p)
+    ops.gemm(a_split, torch.cat([w, w], 1).contiguous(), out_f32=out_s)
+    ref = torch.cat([x1, x2], -1).view(n * hw, C).double() @ w.double().T
+    print(f"\nsplit-precision GEMM operand: plain f16 {rel_l2(out_p.double(), ref):.2e}, [hi | lo] {rel_l2(out_s.double(), ref):.2e}")
+    assert rel_l2(out_s.double(), ref) < 5e-6 < 5e-5 < rel_l2(out_p.double(), ref)
+    # input cast of the stem
+    xa, xb = _rand((n, 4, 7, 5), dev, 71, 30.0), _rand((n, 7, 7, 5), dev, 72)
+    sc = _rand((n,), dev, 73).abs() + 0.5
+    o = torch.full((n, 35, 64), float("nan"), device=dev, dtype=torch.float16)
+    ops.nchw_to_nhwc_f16(xa, xb, o, scale=sc, split=True)
+    v = torch.cat([xa * sc[:, None, None, None], xb], 1).permute(0, 2, 3, 1).reshape(n, 35, 11)
+    assert torch.equal(o[..., :11], v.half()) and torch.equal(o[..., 11:22], (v - v.half().float()).half())
+    assert o[..., 22:].abs().max() == 0
 
 
 @pytest.mark.parametrize("n,hw,c1,c2,silu,dense", GN_CASES)
