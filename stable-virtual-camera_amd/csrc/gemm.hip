@@ -1026,10 +1026,14 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
       (d->K / BK) % 2 == 0 && g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0) {
     const int bn = (g_seva_knobs.gemm_bn > 0 ? g_seva_knobs.gemm_bn == 160 : d->N % 160 == 0) ? 160 : 128;
     const int64_t tiles = ((d->M + 127) / 128) * ((d->N + bn - 1) / bn);
-    SEVA_REQUIRE(tiles < 16383 && d->splitk_ws_bytes >= (int64_t)(16384 + tiles * 128 * bn) * 4 && (uintptr_t)d->splitk_ws % 16 == 0,
-                 "gemm: splitk_ws too small (%lld bytes for %lld tiles) or misaligned", (long long)d->splitk_ws_bytes, (long long)tiles);
-    a.sk_ws = d->splitk_ws;
-    half_m = false;
+    SEVA_REQUIRE((uintptr_t)d->splitk_ws % 16 == 0, "gemm: splitk_ws must be 16-byte aligned");
+    // a workspace that cannot hold this launch's tiles (a larger batch than it was sized for) is not an error: the launch
+    // simply is not split and takes the 64-row-tile kernel it used before split-K existed.  The split decision inside the
+    // capacity range still looks at per-sample dimensions only.
+    if (tiles < 16383 && d->splitk_ws_bytes >= (int64_t)(16384 + tiles * 128 * bn) * 4) {
+      a.sk_ws = d->splitk_ws;
+      half_m = false;
+    }
   }
   if (d->epilogue == 1) {
     // GEGLU tiles are 128 wide (the epilogue pairs 64-row value / gate groups), so the cheaper operand stream comes from the

@@ -298,7 +298,12 @@ class SevaEngine:
         as stream-K: measured slower).  16384 flags + 512 slots of 128 x 160 floats (>= every split-K need here)."""
         if not self.conv_splitk:
             return None
-        return self._buf("sk_ws", (16384 + 512 * 128 * 160,), F32, zero=True)
+        # sized from the launch (never below 512 slots), so that whether a small-image conv is split depends on the per-sample
+        # image size only and not on how many samples are batched (the library falls back to unsplit tiles when a workspace
+        # cannot hold the launch)
+        tiles = max(512, ((rows + 127) // 128) * ((c + 127) // 128)) if hw and hw <= 128 else 512
+        tiles = min(tiles, 16382)
+        return self._buf("sk_ws", (16384 + tiles * 128 * 160,), F32, zero=True)
 
     def _produced(self, out, st):
         """Record (or forget) the statistics buffer that travels with fp32 tensor `out`."""

@@ -6,7 +6,7 @@ tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp SEVA_HIPGRAPH=0
-args="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae"
+args="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python3 $args > $out/bench_stats.json 2> $out/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python3 $args > /dev/null 2> $out/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python3 $args > /dev/null 2> $out/write.err

@@ -51,6 +51,6 @@ if __name__ == "__main__":
         res["git"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("SEVA_GIT_REV")
     except Exception:
         res["git"] = os.environ.get("SEVA_GIT_REV")
-    res["command"] = os.environ.get("SEVA_TRAFFIC_COMMAND", "SEVA_HIPGRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae")
+    res["command"] = os.environ.get("SEVA_TRAFFIC_COMMAND", "SEVA_HIPGRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-other-configs")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
