@@ -99,6 +99,16 @@ typedef struct seva_gemm_desc {
    * use a given workspace (launches on ONE stream are fine). */
   float* splitk_ws;
   int64_t splitk_ws_bytes;
+  /* optional LayerNorm prologue (ABI 7; reference transformer.py:102-104 `attn1(norm1(x))`): when ln_x is set, `a` is ignored and
+   * the A operand is LayerNorm(ln_x) * ln_gamma + ln_beta over the K columns of the fp32 rows ln_x[M][ldx], normalised in
+   * registers by the A-in-registers kernel (exact two-pass statistics, one f16 rounding: what the LayerNorm kernel's output
+   * had).  Plain mode and epilogue, K <= 320 (K % 64 == 0), f16-only output: the fused QKV projection of the C = 320 level --
+   * its standalone LayerNorm launch and the 139 MB f16 tensor between the two disappear. */
+  const float* ln_x;
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t ldx;
+  float ln_eps;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 /* BASELINE config 5 ("fp8 weights, CDNA4 fp8 MFMA"): the same operator with BOTH operands in OCP e4m3 (a: [M][lda]

@@ -16,6 +16,11 @@ struct SevaGemmArgs {
   const uint8_t* w_exp;   // FP8 kernels: per-output-channel E8M0 scale byte (127 + e): weight row n is q_n * 2^e
   float* sk_ws;           // split-K workspace (flags + raw partial tiles), or null: see gemm.hip
   float* ch_stats;        // optional [ceil(M / 64)][2][N]: per 64-row block and output channel, sum and sum of squares of out_f32
+  const float* ln_x;      // ASTAT kernel only: A = LayerNorm(ln_x[M][ldx]) * ln_gamma + ln_beta over K columns (a is ignored)
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t ldx;
+  float ln_eps;
   int64_t M, N, K;        // FP8 kernels: K, lda, cin count 2-byte units (= pairs of e4m3 elements)
   int64_t lda, ldr, ldo32, ldo16, ldo8;
   int64_t rows_per_group, ldra;

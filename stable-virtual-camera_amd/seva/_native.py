@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("col_scale", c_float), ("col_scale_n", c_int32), ("pad_br_only", c_int32),
         ("w_exp", c_void_p), ("out_f8", c_void_p), ("ldo8", c_int64),
         ("ch_stats", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
+        ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ldx", c_int64), ("ln_eps", c_float),
     ]
 
 

@@ -14,7 +14,7 @@ import pytest
 from conftest import PKG
 
 HIPCC = "/opt/rocm/bin/hipcc"
-KERNEL = re.compile(r"^(_ZN\S*gemm_kernelILi128ELi(?:128|160)ELi1ELi0ELb0ELb0ELb0ELb0ELb1ELi4EE\S*):\s")  # MODE 1, SPLITK = true
+KERNEL = re.compile(r"^(_ZN\S*gemm_kernelILi128ELi(?:128|160)ELi1ELi0ELb0ELb0ELb0ELb0ELb1ELi4E(?:Lb0E)?E\S*):\s")  # MODE 1, SPLITK = true
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")

@@ -123,6 +123,31 @@ def _need_exp_lib(what):
         pytest.skip(f"production libseva_hip.so does not carry {what} (experimental library only)")
 
 
+@pytest.mark.parametrize("M,C,N", [(300, 320, 960), (1000, 64, 192), (515, 256, 768), (130, 128, 384), (4097, 320, 320)])
+def test_gemm_layernorm_prologue(dev, M, C, N):
+    """seva_gemm_desc.ln_x: A = LayerNorm(x) normalised in the A-in-registers kernel's prologue, against (a) the LayerNorm
+    kernel followed by the same GEMM (same math, f16 roundings of the normalised row flip at ties only) and (b) fp32 torch."""
+    from seva import ops
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dev)
+    gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    w = (torch.randn(N, C, generator=g) * C ** -0.5).half().to(dev)
+    bias = (0.2 * torch.randn(N, generator=g)).to(dev)
+    a16 = torch.empty((M, C), device=dev, dtype=torch.float16)
+    ops.layernorm(x, gm, bt, a16)
+    want = torch.empty((M, N), device=dev, dtype=torch.float16)
+    ops.gemm(a16, w, bias=bias, out_f16=want, col_scale=0.18, col_scale_n=C if N >= 2 * C else 0)
+    got = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+    ops.gemm(None, w, bias=bias, out_f16=got, col_scale=0.18, col_scale_n=C if N >= 2 * C else 0, ln_x=x, ln_gamma=gm, ln_beta=bt)
+    ref = F.layer_norm(x, (C,), gm, bt, 1e-5) @ w.float().T + bias
+    if N >= 2 * C:
+        ref[:, :C] *= 0.18
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 3e-4 and rel_l2(got, ref) < 1e-3
+    with pytest.raises(Exception):  # fp32 outputs / residuals stay on the staged-A kernels: asking for the prologue there is an error
+        ops.gemm(None, w, out_f32=torch.empty((M, N), device=dev), ln_x=x, ln_gamma=gm, ln_beta=bt)
+
+
 @pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 4, 64), (777, 960, 640), (4097, 132, 192)])
 def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg, knobs):
