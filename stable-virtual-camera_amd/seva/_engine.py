@@ -116,6 +116,7 @@ class SevaEngine:
         self._stats: dict = {}
         self.conv_splitk = _os.environ.get("SEVA_CONV_SPLITK", "1") != "0"  # 0: 64-row tiles at the 9x9 level (A/B runs)
         self.attn_split = _os.environ.get("SEVA_ATTN_SPLIT_KV", "1") != "0"  # 0: joint attention never K/V-split (A/B runs)
+        self.attn_split_max = max(2, min(4, int(_os.environ.get("SEVA_ATTN_SPLIT", "2"))))  # workspace slots (knob attn_split: 2..4)
         # 1: LayerNorm in the prologue of the C = 320 QKV projection (seva_gemm_desc.ln_x).  OFF by default -- measured neutral to
         # negative (tools/kqkv_ln.py, profiles/r03_kqkv_ln.log: LayerNorm + QKV 324.7 us vs fused 324.8 us at the 72x72 level; in the
         # step the norm class drops 0.75 ms and the GEMM class rises 1.0 ms): inside the GEMM the 160 KB of fp32 rows per workgroup
@@ -123,8 +124,10 @@ class SevaEngine:
         self.qkv_ln_fused = _os.environ.get("SEVA_QKV_LN_FUSED", "0") == "1"
         # Split-precision operands (hi + lo f16 pairs against duplicated weights) for the three operand roundings that dominate the
         # network's error budget (tests/test_f16_floor_cpu.py: 1x1 skip convs 4.9e-4, stem 2.4e-4, head 2.3e-4 of 8.1e-4):
-        # comma list of "stem", "head", "skip"; "" = every operand plain fp16 (the round-2 numerics).
-        sp = _os.environ.get("SEVA_SPLIT_PRECISION", "stem,head,skip")
+        # comma list of "stem", "head", "skip" / "skip_deep"; "none" = every operand plain fp16 (the round-2 numerics).
+        # "skip_deep" = the skip convs below the top level only (cout >= 640: 11 of the 14, where M is small and the doubled K and
+        # the extra lo half of the raw input cost ~0.3 ms per step; the three 72x72 ones cost ~0.8 ms for 3.6e-4 of the error budget).
+        sp = _os.environ.get("SEVA_SPLIT_PRECISION", "stem,head,skip_deep")
         self.split = {t for t in sp.split(",") if t} if not self.fp8 else set()
         self.p = model.params
         self.layout: Layout = model._layout
@@ -141,6 +144,10 @@ class SevaEngine:
         self.slice_frames = int(os.environ.get("SEVA_SLICE_FRAMES", "0"))
         self.slice_min_bytes = int(float(os.environ.get("SEVA_SLICE_MIN_MB", "96")) * (1 << 20))
         self.slice_attn = os.environ.get("SEVA_SLICE_ATTN", "0") == "1"  # also slice LN -> QKV -> attention -> out-proj
+
+    def _split_skip(self, cout: int) -> bool:
+        """Does the 1x1 skip conv of a ResBlock with `cout` output channels take its raw input in split precision?"""
+        return "skip" in self.split or ("skip_deep" in self.split and cout >= 2 * self.p.model_channels)
 
     # ------------------------------------------------------------------ packing
     def _pack(self, model) -> None:
@@ -242,7 +249,7 @@ class SevaEngine:
                 if spec.cin != spec.cout:
                     ws = f16(pfx + ".skip_connection.weight").reshape(spec.cout, spec.cin)
                     # split precision: the raw input arrives as [hi | lo] (K = 2 cin), the weights are duplicated
-                    W[pfx + ".skip.w"] = (torch.cat([ws, ws], 1) if "skip" in self.split else ws).contiguous()
+                    W[pfx + ".skip.w"] = (torch.cat([ws, ws], 1) if self._split_skip(spec.cout) else ws).contiguous()
                     W[pfx + ".skip.b"] = f32(pfx + ".skip_connection.bias")
             elif spec.kind == "mvt":
                 pack_ln(pfx + ".norm")
@@ -389,7 +396,7 @@ class SevaEngine:
         cin8, cout8 = _pad128(cin), _pad128(cout)  # fp8 convs see channel counts padded to a multiple of 128 (pad stays zero)
         a8 = self._buf("gn8", (n, hw, cin8), U8, zero=True) if f8_1 else None
         # the 1x1 skip conv (cin != cout) consumes the raw input as f16: emitted by the same GroupNorm pass
-        sp_skip = "skip" in self.split and cin != cout
+        sp_skip = cin != cout and self._split_skip(cout)
         xs16 = self._buf("skip16", (n * hw, (2 if sp_skip else 1) * cin), F16) if cin != cout else None
         s1, s2 = self._gn_stats(x1, x2)
         ops.groupnorm(x1, x2, W[pfx + ".in_layers.0.g"], W[pfx + ".in_layers.0.b"], a16, self.gn_ws,
@@ -473,7 +480,7 @@ class SevaEngine:
             # long key sequences (L = T hw >= 6144) run K/V-split: the workspace for the two partial results
             sws = None
             if self.attn_split and T * hw >= ops.ATTN_SPLIT_MIN_LK:
-                sws = self._buf("attn_split", (ops.attention_split_workspace_numel(n // T, heads, T * hw),), F32)
+                sws = self._buf("attn_split", (ops.attention_split_workspace_numel(n // T, heads, T * hw, self.attn_split_max),), F32)
             ops.attention(q, k, v, att, nb0=n // T, nb1=1, heads=heads, lq=T * hw, lk=T * hw,
                           q_strides=(T * hw * c3, 0, c3), k_strides=(T * hw * c3, 0, c3),
                           o_strides=(T * hw * c, 0, c), q_prescaled=True, split_ws=sws)
