@@ -109,6 +109,13 @@ typedef struct seva_gemm_desc {
   const float* ln_beta;
   int64_t ldx;
   float ln_eps;
+  /* optional second A operand of a 3x3 convolution (ABI 7; mode 1, no upsample): a2 [M][lda2] f16 whose K2 columns (K2 % 64 == 0)
+   * FOLLOW the nine taps in the reduction, K = 9 * cin + K2 and w = [w_conv | w_2] per output row.  Folds the ResBlock's 1x1
+   * skip convolution (seva/modules/layers.py:137-139: `skip_connection(x) + h`) into its second 3x3 conv: one accumulation, no
+   * fp32 round trip of the skip result, one launch fewer. */
+  const void* a2;
+  int64_t lda2;
+  int64_t K2;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 /* BASELINE config 5 ("fp8 weights, CDNA4 fp8 MFMA"): the same operator with BOTH operands in OCP e4m3 (a: [M][lda]

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   // dimensions only).
   // (its own instantiation, SPLITK: the 128x160 kernels have no registers to spare for it)
   constexpr bool SPLIT_OK = SPLITK;
-  static_assert(!SPLITK || (EPI == 0 && !PAIRED && !ASTAT && !DBGK && MODE != 2 && BM == 128), "split-K: plain f32 epilogue only");
+  static_assert(!SPLITK || (EPI == 0 && !PAIRED && !ASTAT && !DBGK && MODE != 2 && MODE != 3 && BM == 128), "split-K: plain f32 epilogue only");
   const int nk_all = (int)(p.K / BK);
   int sk_half = -1, kb = 0, ke = nk_all;  // this block's K-tile range [kb, ke)
   int bid = blockIdx.x;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   const int sr = lane >> 3, sp = lane & 7;
   constexpr int AP = A_PASSES > 0 ? A_PASSES : 1;  // (ASTAT stages no A tile)
   // MODE 0 plain GEMM; MODE 1 conv3x3 (fast gather: per-lane base pointer + 9-bit tap-validity mask, tap offsets are
-  // workgroup-uniform scalars); MODE 2 conv3x3 with the fused nearest-2x upsample (general per-tap address math)
+  // workgroup-uniform scalars); MODE 2 conv3x3 with the fused nearest-2x upsample (general per-tap address math);
+  // MODE 3 = MODE 1 followed by K-tiles of a second plain operand (seva_gemm_desc.a2: the folded 1x1 skip conv)
   const half_t* a_ptr[AP];         // MODE 0: running source pointer; MODE 1: pixel (oy*stride - pad, ox*stride - pad)
   unsigned a_mask[AP];             // MODE 1: bit (3*ky + kx) set = tap inside the image
   int a_by[AP], a_bx[AP];          // MODE 2: top-left input coords (conv-input space)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
       a_bx[i] = ox * p.stride - p.pad_lo;
       a_img[i] = (int64_t)img * p.ih * p.iw * p.cin;
       a_ptr[i] = nullptr;
-      if (MODE == 1) {
+      if (MODE == 1 || MODE == 3) {
         // may point outside the image for border pixels: only dereferenced for taps whose mask bit is set
         a_ptr[i] = p.a + a_img[i] + ((int64_t)a_by[i] * p.iw + a_bx[i]) * p.cin + q * 8;
 #pragma unroll
@@ -253,7 +254,17 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
           ++st_ky;
         }
       }
-      if (MODE == 1) {
+      if (MODE == 3 && kt >= p.nk1) {
+        // MODE 3: the K-tiles behind the nine taps come from a SECOND, plain row-major operand a2 [M][lda2] (the ResBlock's 1x1
+        // skip conv folded into its second 3x3 conv: one accumulation, no fp32 round trip of the skip result).  Addresses are
+        // formed per K-tile (a handful of VALU for the few extra tiles) so that no pointer array stays live next to the gather's.
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+          int64_t m = m0 + wave * (BM / NW) + 8 * i + sr;
+          if (m >= p.M) m = p.M - 1;
+          glds16(p.a2 + m * p.lda2 + (int64_t)(kt - p.nk1) * BK + a_q[i] * 8, la + i * 1024);
+        }
+      } else if (MODE == 1 || MODE == 3) {
         const int64_t tap_off = ((int64_t)ky * p.iw + kx) * p.cin + ci0;  // elements, workgroup-uniform
         const unsigned bit = 1u << (3 * ky + kx);
 #pragma unroll
@@ -1035,7 +1046,16 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   SEVA_REQUIRE(a.ldra % 4 == 0, "gemm: ld_row_add must be a multiple of 4");
   if (d->mode == 1) {
     SEVA_REQUIRE(d->cin > 0 && d->cin % (64 * KU) == 0, "conv: cin=%d not a multiple of %d", d->cin, 64 * KU);
-    SEVA_REQUIRE(d->K == 9LL * d->cin, "conv: K=%lld != 9*cin", (long long)d->K);
+    SEVA_REQUIRE(d->K == 9LL * d->cin + (d->a2 ? d->K2 : 0), "conv: K=%lld != 9*cin (+ K2)", (long long)d->K);
+    if (d->a2) {
+      SEVA_REQUIRE(!FP8 && !d->upsample && d->K2 > 0 && d->K2 % 64 == 0 && d->lda2 >= d->K2 && d->lda2 % 8 == 0 &&
+                       (uintptr_t)d->a2 % 16 == 0 && d->N > 32 && d->out_f32,
+                   "conv: the folded second operand a2 needs the f16 stride-any 3x3 conv without upsample, K2 %% 64 == 0, lda2 >= K2 "
+                   "(multiple of 8), N > 32, an fp32 output");
+      a.a2 = (const half_t*)d->a2;
+      a.lda2 = d->lda2;
+      a.nk1 = (int)(9LL * d->cin / BK);
+    }
     SEVA_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
     SEVA_REQUIRE(!(d->upsample && d->stride != 1), "conv: upsample needs stride 1");
     const int eh = d->upsample ? 2 * d->ih : d->ih, ew = d->upsample ? 2 * d->iw : d->iw;
@@ -1054,9 +1074,10 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
   // algorithmic HBM bytes: A (conv: the NHWC image) and W read once, residual read once, each output written once
   const double a_elems = (d->mode == 1 ? (double)d->n * d->ih * d->iw * d->cin : (double)d->M * (double)d->K) * (d->ln_x ? 2.0 : 1.0);
+  const double a2_bytes = (d->mode == 1 && d->a2) ? 2.0 * (double)d->M * (double)d->K2 : 0.0;
   const double n_out = d->epilogue == 1 ? (double)d->N / 2 : (double)d->N;
   const double esz = FP8 ? 1.0 : 2.0;
-  const double alg_bytes = esz * a_elems + esz * (double)d->N * (double)d->K + (d->bias ? 4.0 * (double)d->N : 0.0) +
+  const double alg_bytes = esz * a_elems + a2_bytes + esz * (double)d->N * (double)d->K + (d->bias ? 4.0 * (double)d->N : 0.0) +
                            (double)d->M * n_out * ((d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) +
                                                    (d->out_f16 ? 2.0 : 0.0) + (d->out_f8 ? 1.0 : 0.0));
   SevaProfScope prof(d->mode == 1 ? 1 : 0, flops, s, alg_bytes);
@@ -1097,10 +1118,12 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   if (g_seva_knobs.gemm_bm > 0) half_m = g_seva_knobs.gemm_bm == 64;
   if (d->ch_stats) half_m = false;  // statistics are emitted per wave-owned 64-row block: 128-row tiles only
   if (d->ln_x) half_m = false;      // the LayerNorm prologue lives in the 128-row A-in-registers kernel
+  const bool two_src = d->mode == 1 && d->a2 != nullptr;  // MODE 3: instantiated for 128- and 160-row tiles, never split-K
+  if (two_src) half_m = false;
   // Split-K = 2 for convolutions over SMALL IMAGES (<= 128 output pixels per sample: the ds8 level, 9 x 9) with a long
   // reduction: 128-row tiles, two workgroups per tile, instead of 64-row tiles.  The choice looks at per-sample dimensions
   // only, so a sample's result does not depend on the batch size.
-  if (d->splitk_ws && d->mode == 1 && !d->upsample && !narrow && (int64_t)d->oh * d->ow <= 128 && d->K / BK >= 16 &&
+  if (d->splitk_ws && d->mode == 1 && !two_src && !d->upsample && !narrow && (int64_t)d->oh * d->ow <= 128 && d->K / BK >= 16 &&
       (d->K / BK) % 2 == 0 && g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0) {
     const int bn = (g_seva_knobs.gemm_bn > 0 ? g_seva_knobs.gemm_bn == 160 : d->N % 160 == 0) ? 160 : 128;
     const int64_t tiles = ((d->M + 127) / 128) * ((d->N + bn - 1) / bn);
@@ -1168,9 +1191,12 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
 #endif
     const bool big = g_seva_knobs.gemm_bm == 160 ||
                      (g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0 && !dbg_run && !half_m && d->M >= 2048);
-    if (big && wide && !narrow && !d->ch_stats && !d->upsample && !a.sk_ws && !f16_only)
+    if (big && wide && !narrow && !d->ch_stats && !d->upsample && !a.sk_ws && !f16_only) {
+      if (two_src) return launch_p<160, 160, 3, 0, false>(a, s);
       return d->mode == 0 ? launch_p<160, 160, 0, 0, false>(a, s) : launch_p<160, 160, 1, 0, false>(a, s);
+    }
   }
+  if (two_src) return wide ? launch<128, 160, 3, 0>(a, s) : launch<128, 128, 3, 0>(a, s);
   if (d->mode == 0) {
     if (narrow) return launch<128, 32, 0, 0>(a, s);
     if (half_m) return wide ? launch<64, 160, 0, 0>(a, s) : launch<64, 128, 0, 0>(a, s);

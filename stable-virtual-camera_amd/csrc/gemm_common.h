@@ -16,6 +16,9 @@ struct SevaGemmArgs {
   const uint8_t* w_exp;   // FP8 kernels: per-output-channel E8M0 scale byte (127 + e): weight row n is q_n * 2^e
   float* sk_ws;           // split-K workspace (flags + raw partial tiles), or null: see gemm.hip
   float* ch_stats;        // optional [ceil(M / 64)][2][N]: per 64-row block and output channel, sum and sum of squares of out_f32
+  const half_t* a2;       // MODE 3: second A operand [M][lda2] whose K2 columns follow the conv's 9 * cin (K = 9 cin + K2)
+  int64_t lda2;
+  int32_t nk1;            // MODE 3: K-tiles of the conv part (9 * cin / 64)
   const float* ln_x;      // ASTAT kernel only: A = LayerNorm(ln_x[M][ldx]) * ln_gamma + ln_beta over K columns (a is ignored)
   const float* ln_gamma;
   const float* ln_beta;

@@ -122,6 +122,9 @@ class SevaEngine:
         # step the norm class drops 0.75 ms and the GEMM class rises 1.0 ms): inside the GEMM the 160 KB of fp32 rows per workgroup
         # are latency-exposed loads in two 80-register batches, where the LayerNorm kernel streams at 5.3 TB/s.
         self.qkv_ln_fused = _os.environ.get("SEVA_QKV_LN_FUSED", "0") == "1"
+        # the ResBlock's 1x1 skip conv as extra K-tiles of its second 3x3 conv (one accumulation, no fp32 round trip of the skip
+        # result, a launch fewer); 0 = separate GEMM + residual (A/B runs).  Not at levels whose convs run split-K (images <= 128 px).
+        self.fold_skip = _os.environ.get("SEVA_FOLD_SKIP", "0") != "0" and not self.fp8
         # Split-precision operands (hi + lo f16 pairs against duplicated weights) for the three operand roundings that dominate the
         # network's error budget (tests/test_f16_floor_cpu.py: 1x1 skip convs 4.9e-4, stem 2.4e-4, head 2.3e-4 of 8.1e-4):
         # comma list of "stem", "head", "skip" / "skip_deep"; "none" = every operand plain fp16 (the round-2 numerics).
@@ -251,6 +254,10 @@ class SevaEngine:
                     # split precision: the raw input arrives as [hi | lo] (K = 2 cin), the weights are duplicated
                     W[pfx + ".skip.w"] = (torch.cat([ws, ws], 1) if self._split_skip(spec.cout) else ws).contiguous()
                     W[pfx + ".skip.b"] = f32(pfx + ".skip_connection.bias")
+                    if self.fold_skip:
+                        # the skip conv folded into conv2 (seva_gemm_desc.a2): weights [w_conv2 | w_skip] per output row, biases summed
+                        W[pfx + ".conv2.wf"] = torch.cat([W[pfx + ".conv2.w"], W[pfx + ".skip.w"]], 1).contiguous()
+                        W[pfx + ".conv2.bf"] = (W[pfx + ".conv2.b"] + W[pfx + ".skip.b"]).contiguous()
             elif spec.kind == "mvt":
                 pack_ln(pfx + ".norm")
                 W[pfx + ".proj_in.w"], W[pfx + ".proj_in.b"] = f16(pfx + ".proj_in.weight"), f32(pfx + ".proj_in.bias")
@@ -416,7 +423,10 @@ class SevaEngine:
         b8 = self._buf("gn8", (n, hw, cout8), U8, zero=True) if f8_2 else None
         ops.groupnorm(hmid, None, W[pfx + ".out_layers.0.g"], W[pfx + ".out_layers.0.b"], b16, self.gn_ws,
                       eps=1e-5, silu=True, out_f8=b8, stats1=st_mid)
-        if cin != cout:
+        fold = cin != cout and self.fold_skip and not f8_2 and (hw > 128 or not self.conv_splitk)
+        if fold:
+            res = None
+        elif cin != cout:
             res = self._buf("skip32", (n * hw, cout), F32)
             ops.gemm(xs16, W[pfx + ".skip.w"], bias=W[pfx + ".skip.b"], out_f32=res)
         else:
@@ -424,7 +434,10 @@ class SevaEngine:
             res = x1
         out = self._buf("out:" + pfx, (n, hw, cout), F32)
         st_out = self._stats_buf("out:" + pfx, n * hw, hw, cout)
-        if f8_2:
+        if fold:
+            ops.conv3x3(b16.view(n, h, w, cout), W[pfx + ".conv2.wf"], bias=W[pfx + ".conv2.bf"], a2=xs16, out_f32=out,
+                        ch_stats=st_out)
+        elif f8_2:
             ops.conv3x3(b8.view(n, h, w, cout8), W[pfx + ".conv2.w8"], w_exp=W[pfx + ".conv2.w8e"], bias=W[pfx + ".conv2.b"],
                         residual=res, out_f32=out, ch_stats=st_out)
         else:

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("w_exp", c_void_p), ("out_f8", c_void_p), ("ldo8", c_int64),
         ("ch_stats", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
         ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ldx", c_int64), ("ln_eps", c_float),
+        ("a2", c_void_p), ("lda2", c_int64), ("K2", c_int64),
     ]
 
 

@@ -202,8 +202,11 @@ def conv3x3(
     w_exp: torch.Tensor | None = None,
     ch_stats: torch.Tensor | None = None,
     splitk_ws: torch.Tensor | None = None,
+    a2: torch.Tensor | None = None,
 ) -> None:
     """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16.
+    a2 ([M, K2] f16, K2 % 64 == 0): a second operand folded into the reduction behind the nine taps, w: [cout, 9*cin + K2]
+    (seva_gemm_desc.a2: the ResBlock's 1x1 skip conv inside its second 3x3 conv).
     pad_br_only: zero padding at the bottom / right edge only (diffusers Downsample2D, pad (0,1,0,1)).
     fp8 mode (w_exp given): x and w are uint8 tensors of e4m3 bytes, cin % 128 == 0, no fused upsample."""
     require_cuda(x, w)
@@ -218,6 +221,11 @@ def conv3x3(
     d.bias, d.row_add, d.residual = ptr(bias), ptr(row_add), ptr(residual)
     d.out_f32, d.out_f16 = ptr(out_f32), ptr(out_f16)
     d.M, d.N, d.K = n * oh * ow, w.shape[0], 9 * cin
+    if a2 is not None:
+        assert not fp8 and not upsample and a2.dtype == F16 and a2.dim() == 2 and a2.stride(1) == 1 and a2.shape[0] == n * oh * ow
+        d.a2, d.lda2, d.K2 = a2.data_ptr(), a2.stride(0), a2.shape[1]
+        d.K = 9 * cin + a2.shape[1]
+    assert w.shape[1] == d.K
     d.lda = cin
     d.ldr = residual.stride(-2) if residual is not None else 0
     d.ldo32 = out_f32.stride(-2) if out_f32 is not None else 0

@@ -127,8 +127,12 @@ def ff_fused(a, w1, b1, w2, b2, *, residual=None, out_f32=None, out_f16=None, ln
 
 def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
             ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None, ch_stats=None,
-            splitk_ws=None):
+            splitk_ws=None, a2=None):
     n, ih, iw, cin = x.shape
+    w2 = None
+    if a2 is not None:  # folded second operand (seva_gemm_desc.a2): the columns behind the nine taps multiply a2
+        assert w_exp is None and not upsample and a2.dtype == F16 and a2.shape[1] % 64 == 0 and w.shape[1] == 9 * cin + a2.shape[1]
+        w, w2 = w[:, : 9 * cin], w[:, 9 * cin:]
     if w_exp is not None:  # seva_gemm_fp8, conv mode
         assert x.dtype == U8 and w.dtype == U8 and cin % 128 == 0 and w.shape[1] == 9 * cin and not upsample
         x, w = _from_fp8(x), dequantize_weight_fp8(w, w_exp)
@@ -144,6 +148,8 @@ def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per
         y = F.conv2d(xi, wk, None, stride=stride, padding=1)
     N = w.shape[0]
     acc = y.permute(0, 2, 3, 1).reshape(-1, N)
+    if w2 is not None:
+        acc = acc + a2.float() @ w2.float().T
     _epilogue(acc, acc.shape[0], N, bias, row_add, rows_per_group, ld_row_add, residual, out_f32,
               out_f16, False, ch_stats=ch_stats)
 

@@ -687,6 +687,31 @@ def test_conv_channel_stats(dev, n, ih, iw, cin, cout, stride, up):
     assert torch.equal(st.double(), _block_stats(o32, M, cout))
 
 
+@pytest.mark.parametrize("n,ih,iw,cin,cout,k2,stats", [(3, 12, 10, 64, 128, 64, False), (2, 16, 16, 128, 320, 192, True),
+                                                       (42, 18, 18, 128, 160, 128, False), (2, 40, 36, 64, 64, 128, True),
+                                                       (16, 24, 24, 64, 320, 256, False)])
+def test_conv3x3_with_folded_second_operand(dev, n, ih, iw, cin, cout, k2, stats):
+    """seva_gemm_desc.a2 (MODE 3): out = conv3x3(x, w_conv) + a2 @ w_2^T (+ bias) in ONE accumulation, w = [w_conv | w_2].
+    Integer data: bit-exact against torch, including the epilogue-emitted GroupNorm statistics; every tile shape of the mode
+    (160 x 160 for big wide launches, 128 x 160, 128 x 128) is reached by the parametrisation."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    M = n * ih * iw
+    x = _ints((n, ih, iw, cin), -2, 2, dev, 1).half()
+    wc = _ints((cout, cin, 3, 3), -1, 1, dev, 2)
+    a2 = _ints((M, k2), -2, 2, dev, 3).half()
+    w2 = _ints((cout, k2), -1, 1, dev, 4)
+    bias = _ints((cout,), -3, 3, dev, 5)
+    wcat = torch.cat([pack_conv3x3(wc).half().to(dev), w2.half()], 1).contiguous()
+    o = torch.full((M, cout), float("nan"), device=dev)
+    st = torch.full(ops.channel_stats_shape(M, cout), float("nan"), device=dev) if stats and (ih * iw) % 64 == 0 else None
+    ops.conv3x3(x, wcat, bias=bias, a2=a2, out_f32=o, ch_stats=st)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wc, bias, padding=1).permute(0, 2, 3, 1).reshape(M, cout) + a2.float() @ w2.T
+    assert torch.equal(o, ref), f"max diff {(o - ref).abs().max()}"
+    if st is not None:
+        assert torch.equal(st.double(), _block_stats(o, M, cout))
+
+
 @pytest.mark.parametrize("n,ih,iw,cin,cout,stride", [(42, 9, 9, 1280, 1280, 1), (5, 9, 9, 256, 320, 1), (42, 18, 18, 640, 1280, 2),
                                                       (3, 8, 16, 128, 128, 1), (1, 4, 4, 2560, 160, 1)])
 def test_conv_splitk_small_images(dev, n, ih, iw, cin, cout, stride):

@@ -96,3 +96,78 @@ def test_trajectory_168_views_full_size_one_gpu(dev):
         assert torch.equal(zz[slot], z[fid])
     print(f"\n168-view trajectory, 1.3B @ 576x576, {steps} steps/window: {len(plan.pass1)}+{len(plan.pass2)} windows in "
           f"{timers['gather'] - timers['start']:.2f} s")
+
+
+def _cfg_split_worker(rank, world, port, q, n, hw, T, steps):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from test_model_gpu import _build
+    from seva import pipeline
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+    dev = torch.device("cuda:0")  # both ranks on the one card of this box: gloo carries the collectives (RCCL refuses that)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net, _ = _build("tiny", dev)
+    c2ws, Ks = synth.orbit_c2w(n), synth.default_K(n)
+    g = torch.Generator().manual_seed(3)
+    lat = (torch.randn(1, 4, hw, hw, generator=g) * 0.9).to(dev)
+    tok = torch.randn(1024, generator=g)
+    tok = (tok / tok.norm()).to(dev)
+    with torch.no_grad():
+        res = pipeline.run_trajectory(SGMWrapper(net), lat, c2ws, Ks, [0], clip_token=tok, T=T, num_steps=steps, device=dev,
+                                      cfg_split=True)
+    q.put((rank, res["latents"].cpu().numpy() if "latents" in res else None,
+           {f: v.cpu().numpy() for f, v in res["anchor_latents"].items()} if "anchor_latents" in res else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg_split_on_the_hip_path_equals_single_process(dev):
+    """CFG-split on REAL kernels: two ranks (both on this box's one card, gloo for the collectives) run the first-pass window
+    and -- the trajectory has an odd number of second-pass windows -- the last second-pass window as CFG halves with one
+    all-gather per step; the trajectory equals the single-process one BIT FOR BIT.  This is the property that makes the split a
+    pure scheduling decision: a half batch is bitwise the corresponding half of the full batch through every HIP kernel."""
+    import socket
+    import torch.multiprocessing as mp
+    from test_model_gpu import _build
+    from seva import pipeline
+    from seva import synthetic as synth
+    from seva.model import SGMWrapper
+    n, hw, T, steps = 100, 16, 21, 3
+    c2ws, Ks = synth.orbit_c2w(n), synth.default_K(n)
+    plan = pipeline.plan_trajectory(c2ws, [0], T=T)
+    sched = pipeline.second_pass_schedule(len(plan.pass2), 2, True)
+    assert any(len(ranks) == 2 for r in sched for _, ranks in r), sched
+    net, _ = _build("tiny", dev)
+    g = torch.Generator().manual_seed(3)
+    lat = (torch.randn(1, 4, hw, hw, generator=g) * 0.9).to(dev)
+    tok = torch.randn(1024, generator=g)
+    tok = (tok / tok.norm()).to(dev)
+    with torch.no_grad():
+        ref_res = pipeline.run_trajectory(SGMWrapper(net), lat, c2ws, Ks, [0], clip_token=tok, T=T, num_steps=steps, device=dev)
+    ref = ref_res["latents"].cpu()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import os
+    from conftest import PKG, ROOT
+    here = os.path.dirname(os.path.abspath(__file__))
+    os.environ["PYTHONPATH"] = os.pathsep.join([PKG, ROOT, here, os.environ.get("PYTHONPATH", "")])  # for the spawned workers
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfg_split_worker, args=(r, 2, port, q, n, hw, T, steps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = torch.from_numpy(res[0][1])
+    assert res[1][1] is None and torch.isfinite(got).all()
+    if not torch.equal(got, ref):  # say where: the first-pass anchors (the CFG-split window) or a second-pass window
+        anc = {f: float((torch.from_numpy(v) - ref_res["anchor_latents"][f].cpu()).abs().max()) for f, v in res[0][2].items()}
+        per_win = [(i, max(float((got[f] - ref[f]).abs().max()) for f in w.target_ids)) for i, w in enumerate(plan.pass2)]
+        raise AssertionError(f"anchors (pass 1) max diff {max(anc.values()):.3e}; second-pass windows {per_win}")
