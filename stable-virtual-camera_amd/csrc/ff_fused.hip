@@ -317,8 +317,11 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int e = 0; e < 2; ++e) sum += v[ks][e][0] + v[ks][e][1] + v[ks][e][2] + v[ks][e][3];
+      // (each cross-lane result is first read by a plain 32-bit op: see the note at the GroupNorm modulation, norm.hip)
       sum += __shfl_xor(sum, 16, 64);
+      asm volatile("" : "+v"(sum));
       sum += __shfl_xor(sum, 32, 64);
+      asm volatile("" : "+v"(sum));
       const float mean = sum / (float)C;
       float ss = 0.f;
 #pragma unroll
@@ -331,7 +334,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
             ss += dlt * dlt;
           }
       ss += __shfl_xor(ss, 16, 64);
+      asm volatile("" : "+v"(ss));
       ss += __shfl_xor(ss, 32, 64);
+      asm volatile("" : "+v"(ss));
       const float rstd = rsqrtf(ss / (float)C + p.ln_eps);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {

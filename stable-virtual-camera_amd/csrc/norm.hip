@@ -267,24 +267,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
           for (int j = 0; j < ND; ++j) dn[u][j] = (j < dc) ? dp[j] : 0.f;
         }
       }
-      // Two phases.  The SiLU's transcendentals (v_exp_f32 / v_rcp_f32) are all consumed, by plain 32-bit VALU ops, BEFORE the
-      // first packed-fp32 op of the modulation issues: with v_pk_fma_f32 issuing under a pending transcendental this kernel lost
-      // the last 16 lanes of one result register now and then while a second process ran on the same card (DESIGN.md section 4,
-      // profiles/r03_two_process_groupnorm.log; tests/test_isa_trans_pk_cpu.py keeps the two apart in this kernel)
-      float ys[U][4];
+      // The Pluecker component is broadcast into a REAL register pair (two v_mov) rather than read through op_sel from the
+      // registers the load returned into: with `v_pk_fma_f32 ... op_sel` reading freshly loaded registers this kernel now and then
+      // computed one (pixel, channel-of-the-quad) wrong in the last 16 lanes of a wave whenever OTHER work ran on the card at the
+      // same time (a second stream or a second process; never alone).  Measured variant by variant (DESIGN.md section 4,
+      // profiles/r03_groupnorm_concurrency_variants.log): plain FMAs, this form and volatile loads are clean, every op_sel form
+      // shows it in 10-25 % of the launches.
+      f32x2 dn2[U][ND];
+      if (dc) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float y = v[u][r] * a[r] + b[r];
-          if (p.silu) {
-            asm volatile("" : "+v"(y));  // one value per register: keeps the SLP vectoriser from packing the SiLU itself
-            y = silu_f(y);
-            asm volatile("" : "+v"(y));
+          for (int j = 0; j < ND; ++j) {
+            dn2[u][j] = f32x2{dn[u][j], dn[u][j]};
+            asm volatile("" : "+v"(dn2[u][j]));
           }
-          ys[u][r] = y;
-        }
-      if (DENSE) __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int pix = pix0 + u * pl_count;
@@ -292,12 +290,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
         float y4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float y = ys[u][r];
+          float y = v[u][r] * a[r] + b[r];
+          if (p.silu) y = silu_f(y);
           if (dc) {
             f32x2 m = bmod[r];  // (1 + scale, shift)
 #pragma unroll
-            for (int j = 0; j < ND; ++j)
-              m = __builtin_elementwise_fma(wmod[r][j], f32x2{dn[u][j], dn[u][j]}, m);
+            for (int j = 0; j < ND; ++j) m = __builtin_elementwise_fma(wmod[r][j], dn2[u][j], m);
             y = y * m[0] + m[1];
           }
           h[r] = (half_t)y;

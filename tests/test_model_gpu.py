@@ -152,6 +152,57 @@ def test_forward_is_deterministic_and_graph_replayable(dev, tiny):
     assert torch.equal(out, a)
 
 
+def test_forward_is_repeatable_while_a_second_stream_keeps_the_card_busy(dev):
+    """Round 3: with other work on the card (a second stream here, a second process in the CFG-split test) two kernels -- the modulated
+    GroupNorm apply and the fused feed-forward's LayerNorm prologue -- computed a stale value in the last 16 lanes of a wave now and then
+    (27 of 149 forwards differed; alone every run was bit-equal).  Fixed in the kernels (tests/test_isa_concurrency_cpu.py, DESIGN.md
+    section 4); this is the run-time check: 60 forwards under load, every one bit-equal to the first."""
+    import threading
+    import time
+    net, _ = _build("tiny", dev)
+    eng = net.engine()
+    eng.use_graph = False
+    T, hw = 21, 16
+
+    def inputs(seed):
+        g = torch.Generator().manual_seed(seed)
+        n = 2 * T
+        return ((torch.randn(n, 4, hw, hw, generator=g) * 10).to(dev), torch.randn(n, 7, hw, hw, generator=g).to(dev),
+                torch.full((n,), 700, dtype=torch.int64, device=dev), torch.randn(n, 1, 1024, generator=g).to(dev),
+                torch.randn(n, 6, hw * 8, hw * 8, generator=g).to(dev))
+
+    stop = []
+    started = threading.Event()
+
+    def load():
+        s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            net2, _ = _build("tiny", dev, seed=1)
+            eng2 = net2.engine()
+            eng2.use_graph = False
+            a2 = inputs(11)
+            while not stop:
+                for _ in range(10):
+                    eng2.forward(*a2, T)
+                s2.synchronize()
+                started.set()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        assert started.wait(120), "the load thread never ran"
+        a = inputs(5)
+        ref = eng.forward(*a, T).clone()
+        differing = 0
+        for _ in range(60):
+            differing += int(not torch.equal(eng.forward(*a, T), ref))
+            time.sleep(0)
+    finally:
+        stop.append(1)
+        th.join()
+    assert differing == 0, f"{differing} of 60 forwards differ from the first while a second stream runs"
+
+
 def test_frame_sliced_execution_is_bitwise_identical(dev, tiny):
     """engine._slice_rows: running the token-wise chains a few frames at a time changes no bit of the output."""
     net, _ = tiny
