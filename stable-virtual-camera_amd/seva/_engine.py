@@ -122,8 +122,9 @@ class SevaEngine:
         # step the norm class drops 0.75 ms and the GEMM class rises 1.0 ms): inside the GEMM the 160 KB of fp32 rows per workgroup
         # are latency-exposed loads in two 80-register batches, where the LayerNorm kernel streams at 5.3 TB/s.
         self.qkv_ln_fused = _os.environ.get("SEVA_QKV_LN_FUSED", "0") == "1"
-        # the ResBlock's 1x1 skip conv as extra K-tiles of its second 3x3 conv (one accumulation, no fp32 round trip of the skip
-        # result, a launch fewer); 0 = separate GEMM + residual (A/B runs).  Not at levels whose convs run split-K (images <= 128 px).
+        # 1: the ResBlock's 1x1 skip conv as extra K-tiles of its second 3x3 conv (one accumulation, no fp32 round trip of the skip
+        # result, a launch fewer).  OFF by default -- measured neutral (profiles/r03_ab_fold_skip.log: 96.9 vs 96.5 ms per step over two
+        # interleaved rounds, GEMM class -2.0 ms, conv class +1.2 ms).  Not at levels whose convs run split-K (images <= 128 px).
         self.fold_skip = _os.environ.get("SEVA_FOLD_SKIP", "0") != "0" and not self.fp8
         # Split-precision operands (hi + lo f16 pairs against duplicated weights) for the three operand roundings that dominate the
         # network's error budget (tests/test_f16_floor_cpu.py: 1x1 skip convs 4.9e-4, stem 2.4e-4, head 2.3e-4 of 8.1e-4):
