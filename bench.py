@@ -30,6 +30,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -192,8 +193,20 @@ def trajectory_leg(net, device, rank, world, n, hw, T, steps, cfg_split):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        prof = None
+        if os.environ.get("SEVA_BENCH_PROFILE_TRAJ") == "1":  # debugging aid: where the host time of the trajectory goes
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         res = pipeline.run_trajectory(wrap, lat, c2ws, Ks, [0], clip_token=tok, T=T, num_steps=steps, device=device,
                                       plan=plan, timers=timers, cfg_split=cfg_split and world > 1)
+        if prof is not None:
+            import io
+            import pstats
+            prof.disable()
+            st = io.StringIO()
+            pstats.Stats(prof, stream=st).sort_stats("cumulative").print_stats(30)
+            print(f"[rank {rank}]", st.getvalue()[:5000], file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -213,6 +226,7 @@ def trajectory_leg(net, device, rank, world, n, hw, T, steps, cfg_split):
         "n_gpus": world, "scaling": "strong", "cfg_split": bool(cfg_split and world > 1), "steps_per_window": steps,
         "wall_s": total, "novel_views_per_sec": (n - 1) / total, "pass1_s": p1, "anchor_allgather_s": ex, "pass2_s": p2,
         "gather_s": ga, "pass2_steps_per_sec": len(plan.pass2) * steps / p2, "pass2_rounds": [len(r) for r in sched],
+        "rank0_window_s": [[ps, i, round(sec, 4)] for ps, i, sec in timers.get("windows", [])],
         "window_times_ceiling": (0.5 if (cfg_split and world > 1) else 1.0) * len(plan.pass1)
                                 + sum(0.5 if len(r[0][1]) == 2 else 1.0 for r in sched),
         "handoff": "anchor latents (no decode/encode round trip); VAE decode of the frames not included",
@@ -361,89 +375,115 @@ def main():
 
     vae = None
     if rank == 0 and not args.no_vae:
-        # VAE decode of finished latents (reference autoencoder.py:40-48, chunk_size=1), outside `value`
-        from seva.modules.autoencoder import AutoEncoder
+        try:
+            # VAE decode of finished latents (reference autoencoder.py:40-48, chunk_size=1), outside `value`
+            from seva.modules.autoencoder import AutoEncoder
 
-        ae = AutoEncoder(chunk_size=1, random_init=True).to(device)
-        zl = (x[:7] / x[:7].std() * 0.18215).contiguous()  # 7 frames per pass (AutoEncoder's default execution chunk)
-        with torch.no_grad():
-            ae.decode(zl)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            img = ae.decode(zl)
-            torch.cuda.synchronize()
-        dtv = (time.perf_counter() - t1) / zl.shape[0]
-        with torch.no_grad():  # encode of the input / anchor views (reference autoencoder.py:21-35), chunk_size=1
-            ae.encode(img)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            ae.encode(img)
-            torch.cuda.synchronize()
-        dte = (time.perf_counter() - t1) / img.shape[0]
-        vae = {"ms_per_frame": dtv * 1e3, "frames_per_sec": 1.0 / dtv, "frame": f"{img.shape[-2]}x{img.shape[-1]}",
-               "encode_ms_per_frame": dte * 1e3, "frames_per_pass": int(zl.shape[0]),
-               "weights": "random-init SD-2.1 VAE topology (parity unpinned)"}
-        del ae
-        # CLIP ViT-H-14 image conditioner (reference conditioner.py:36-39), once per window on the input views, outside `value`
-        from seva.modules.conditioner import CLIPConditioner
+            ae = AutoEncoder(chunk_size=1, random_init=True).to(device)
+            zl = (x[:7] / x[:7].std() * 0.18215).contiguous()  # 7 frames per pass (AutoEncoder's default execution chunk)
+            with torch.no_grad():
+                ae.decode(zl)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                img = ae.decode(zl)
+                torch.cuda.synchronize()
+            dtv = (time.perf_counter() - t1) / zl.shape[0]
+            with torch.no_grad():  # encode of the input / anchor views (reference autoencoder.py:21-35), chunk_size=1
+                ae.encode(img)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ae.encode(img)
+                torch.cuda.synchronize()
+            dte = (time.perf_counter() - t1) / img.shape[0]
+            vae = {"ms_per_frame": dtv * 1e3, "frames_per_sec": 1.0 / dtv, "frame": f"{img.shape[-2]}x{img.shape[-1]}",
+                   "encode_ms_per_frame": dte * 1e3, "frames_per_pass": int(zl.shape[0]),
+                   "weights": "random-init SD-2.1 VAE topology (parity unpinned)"}
+            del ae
+            # CLIP ViT-H-14 image conditioner (reference conditioner.py:36-39), once per window on the input views, outside `value`
+            from seva.modules.conditioner import CLIPConditioner
 
-        clip = CLIPConditioner(random_init=True).to(device)
-        with torch.no_grad():
-            clip(img[:1])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            clip(img[:1])
-            torch.cuda.synchronize()
-        vae["clip_conditioner_ms_per_frame"] = (time.perf_counter() - t1) * 1e3
-        del clip
+            clip = CLIPConditioner(random_init=True).to(device)
+            with torch.no_grad():
+                clip(img[:1])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                clip(img[:1])
+                torch.cuda.synchronize()
+            vae["clip_conditioner_ms_per_frame"] = (time.perf_counter() - t1) * 1e3
+            del clip
+        except Exception as e:  # noqa: BLE001 -- an auxiliary leg never costs the headline line
+            vae = {"error": f"{type(e).__name__}: {e}"[:400]}
 
-    other, traj = None, None
+    # The headline line is complete here.  Everything below (other configs, the strong-scaling trajectory leg, the CPU baseline)
+    # is reported next to it and must never cost it: a leg that raises is recorded as {"error": ...}, and a leg that hangs (a
+    # collective some rank never reaches) is cut by a watchdog that prints the line as it stands and ends the process.
+    flop = FLOP_PER_STEP.get((T, hw))
+    value = world * K / elapsed
+    out = {
+        # the headline name is reserved for the headline shape; other shapes are labelled as what they are
+        "metric": (f"denoising steps/sec, 1.3B Seva @ {T}x{hw * 8}x{hw * 8} views"
+                   + ("" if (T, hw) == (21, 72) else " (NOT the 21x576x576 headline shape)")
+                   + ("" if args.precision == "f16" else " [fp8 weights + activations, BASELINE config 5: not the f16 parity mode]")),
+        "value": value, "unit": "denoising steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16" if args.precision == "f16" else "f8e4m3 (C>=640 levels) + f16 (C=320 level)",
+        "data": "synthetic",
+        "novel_views_per_sec": value * (T - N_INPUT_VIEWS) / NUM_STEPS_PER_WINDOW,
+        "hipgraph": {"whole_step": sampler._step_graphs.captures > 0,
+                     "step_replays": getattr(sampler._step_graphs.graph, "replays", 0),
+                     "network_only": bool(net.engine().use_graph) and sampler._step_graphs.captures == 0},
+        "config": {"workload": f"Seva 1.3B (1,263,968,004 params, random-init), one {T}-view window per GPU, "
+                               f"{hw * 8}x{hw * 8} px (latent {hw}x{hw}), CFG batch {2 * T}, Euler-EDM step, "
+                               "MultiviewCFG(1.2) cfg 2.0; novel_views_per_sec = value x (T - 1 input view) / 50 steps per window",
+                   "views": T, "latent": hw, "windows": world,
+                   "flop_per_step": flop,
+                   "model_tflops": (flop * value / 1e12) if flop else None},
+        "roofline": roofline, "cpu_baseline": None, "vae_decode": vae,
+        "other_configs": None, "trajectory": None,
+        "cond_assembly": {"ms": cond_assembly_ms,
+                          "what": "camera normalisation (host) + Pluecker maps + cond/uc assembly (HIP), once per window, outside `value`; median of 3"},
+    }
+    printed = threading.Lock()
+
+    def emit():
+        if printed.acquire(blocking=False) and rank == 0:
+            print(json.dumps(out), flush=True)
+
+    def watchdog():
+        out["legs_cut_short"] = f"an auxiliary leg did not finish within {leg_limit:.0f} s; the line is printed without it"
+        emit()
+        os._exit(0)
+
+    leg_limit = float(os.environ.get("SEVA_BENCH_LEG_TIMEOUT", "900"))
+    timer = threading.Timer(leg_limit, watchdog)
+    timer.daemon = True
+    timer.start()
+
+    def leg(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
+            return {"error": f"{type(e).__name__}: {e}"[:400]}
+
     if not args.no_other_configs and (T, hw) == (21, 72) and args.precision == "f16":
         if world == 1:
             # BASELINE configs 2, 3, 5 and (on this one GPU) 4 -- outside `value`
-            other = {"config2_T8": steps_leg(net, device, 8, hw, args.other_steps),
-                     "config3_T24_one_window": steps_leg(net, device, 24, hw, args.other_steps)}
+            other = {"config2_T8": leg(steps_leg, net, device, 8, hw, args.other_steps),
+                     "config3_T24_one_window": leg(steps_leg, net, device, 24, hw, args.other_steps)}
             net.set_precision("fp8")
-            leg = steps_leg(net, device, T, hw, args.other_steps)
-            leg["dtype"] = "f8e4m3 (C>=640 levels) + f16 (C=320 level); separate accuracy class, not the parity mode"
-            other["config5_fp8_T21"] = leg
+            r8 = leg(steps_leg, net, device, T, hw, args.other_steps)
+            r8["dtype"] = "f8e4m3 (C>=640 levels) + f16 (C=320 level); separate accuracy class, not the parity mode"
+            other["config5_fp8_T21"] = r8
             net.set_precision("f16")
-            other["config4_trajectory168_one_gpu"] = trajectory_leg(net, device, rank, world, 168, hw, T,
-                                                                    args.leg_traj_steps, False)
+            other["config4_trajectory168_one_gpu"] = leg(trajectory_leg, net, device, rank, world, 168, hw, T, args.leg_traj_steps, False)
+            out["other_configs"] = other
         else:
-            traj = trajectory_leg(net, device, rank, world, 168, hw, T, args.leg_traj_steps, True)
+            out["trajectory"] = leg(trajectory_leg, net, device, rank, world, 168, hw, T, args.leg_traj_steps, True)
 
-    if rank == 0:
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(sd)
-        flop = FLOP_PER_STEP.get((T, hw))
-        value = world * K / elapsed
-        out = {
-            # the headline name is reserved for the headline shape; other shapes are labelled as what they are
-            "metric": (f"denoising steps/sec, 1.3B Seva @ {T}x{hw * 8}x{hw * 8} views"
-                       + ("" if (T, hw) == (21, 72) else " (NOT the 21x576x576 headline shape)")
-                       + ("" if args.precision == "f16" else " [fp8 weights + activations, BASELINE config 5: not the f16 parity mode]")),
-            "value": value, "unit": "denoising steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if args.precision == "f16" else "f8e4m3 (C>=640 levels) + f16 (C=320 level)",
-            "data": "synthetic",
-            "novel_views_per_sec": value * (T - N_INPUT_VIEWS) / NUM_STEPS_PER_WINDOW,
-            "hipgraph": {"whole_step": sampler._step_graphs.captures > 0,
-                         "step_replays": getattr(sampler._step_graphs.graph, "replays", 0),
-                         "network_only": bool(net.engine().use_graph) and sampler._step_graphs.captures == 0},
-            "config": {"workload": f"Seva 1.3B (1,263,968,004 params, random-init), one {T}-view window per GPU, "
-                                   f"{hw * 8}x{hw * 8} px (latent {hw}x{hw}), CFG batch {2 * T}, Euler-EDM step, "
-                                   "MultiviewCFG(1.2) cfg 2.0; novel_views_per_sec = value x (T - 1 input view) / 50 steps per window",
-                       "views": T, "latent": hw, "windows": world,
-                       "flop_per_step": flop,
-                       "model_tflops": (flop * value / 1e12) if flop else None},
-            "roofline": roofline, "cpu_baseline": cpu, "vae_decode": vae,
-            "other_configs": other, "trajectory": traj,
-            "cond_assembly": {"ms": cond_assembly_ms,
-                              "what": "camera normalisation (host) + Pluecker maps + cond/uc assembly (HIP), once per window, outside `value`; median of 3"},
-        }
-        print(json.dumps(out), flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = leg(cpu_baseline, sd)
+    timer.cancel()
+    emit()
     if world > 1:
         dist.barrier()  # rank 0 alone ran the VAE / CPU legs: nobody tears the communicator down under it
         dist.destroy_process_group()

@@ -153,6 +153,14 @@ def _all_gather_padded(local: torch.Tensor, count: int, max_count: int, group=No
 _pair_groups: dict = {}
 
 
+def _now(device) -> float:
+    """Wall clock after the device has drained (per-window times of `run_trajectory(timers=...)`)."""
+    import time
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return time.perf_counter()
+
+
 def cfg_pair_groups(group=None) -> list:
     """Two-rank process groups (0,1), (2,3), ... of `group` (default: the world), created once per process: every rank
     calls this (new_group is collective) and gets the same list; entry j is the group of ranks 2j and 2j+1."""
@@ -283,8 +291,11 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
     got_ids, got_lat = [], []
     for i in mine1:
         win = plan.pass1[i]
+        t_w = _now(device) if timers is not None else 0.0
         z = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index], step_seed=step_seed(win),
                        clip_token=tok(win.source_ids), cfg_split=(pairs[0], rank) if split1 else None, **common)
+        if timers is not None:
+            timers.setdefault("windows", []).append((1, i, _now(device) - t_w))
         zt = handoff_latent(z[win.target_slots], win.target_ids)
         for fid, lat in zip(win.target_ids, zt):
             latents_of[fid] = lat  # a dependent strategy's next window on this rank may read it
@@ -318,9 +329,12 @@ def run_trajectory(denoise_net: Callable, input_latents: torch.Tensor, c2ws: tor
             if rank not in ranks:
                 continue
             win = plan.pass2[i]
+            t_w = _now(device) if timers is not None else 0.0
             outs[i] = run_window(win, latents_of, denoise_net, c2ws, Ks, noise=noises[win.global_index],
                                  step_seed=step_seed(win), clip_token=tok(win.source_ids),
                                  cfg_split=(pairs[ranks[0] // 2], ranks.index(rank)) if len(ranks) == 2 else None, **common)
+            if timers is not None:
+                timers.setdefault("windows", []).append((2, i, _now(device) - t_w))
     mark("pass2")
     # ------------------------------------------------------------------ gather to rank 0, round by round
     collected = {}

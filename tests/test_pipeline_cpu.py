@@ -133,7 +133,7 @@ def test_two_rank_sharded_trajectory_equals_sequential(first_pass, monkeypatch):
     assert res[1][1] is None  # only rank 0 assembles the trajectory
     got = torch.from_numpy(res[0][1])
     assert torch.equal(got, ref), float((got - ref).abs().max())
-    assert res[0][2] == ["exchange", "gather", "pass1", "pass2", "start"]
+    assert res[0][2] == ["exchange", "gather", "pass1", "pass2", "start", "windows"]
 
 
 def test_reference_style_rgb_handoff_and_per_window_clip_token(monkeypatch):
