@@ -441,6 +441,10 @@ class EulerEDMSampler(object):
         cc_half = {k: (v[sl] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == 2 * n else v) for k, v in cc.items()}
         mine = _f32c(denoiser(xx[sl], ss[sl], cc_half))
         both = torch.empty((2 * n,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        if mine.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsal backend only (RCCL is stream-ordered): gloo stages device tensors through the host, and with the half-batch
+            # network still in flight its all-gather took 5.5 s per step on a shared card instead of 3 ms (profiles/r03_bench_n2_rehearsal*)
+            torch.cuda.synchronize(mine.device)
         dist.all_gather_into_tensor(both, mine, group=group)
         return both
 
