@@ -482,10 +482,15 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   const bool active = __builtin_amdgcn_readfirstlane(qb * (32 * QB * NW) + wave * (32 * QB)) < p.lq;
   f32x16 acc_o[QB][2];
   float m_run[QB], l_run[QB];
+  // -m_run as a 16-register block per query block: the C operand of the first score MFMA of every key block (as in attn_kernel),
+  // rebuilt only in the rare rescale branch: 64 v_mov per tile fewer in a loop whose VALU work, not its MFMA work, sets the pace
+  f32x16 neg_m[QB];
 #pragma unroll
   for (int c = 0; c < QB; ++c) {
     m_run[c] = 0.f;
     l_run[c] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) neg_m[c][r] = 0.f;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -553,11 +558,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
         for (int c = 0; c < QB; ++c) {
           if (s == 0) {
-            f32x16 c0;
-            const float init = -m_run[c];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c0[r] = init;
-            sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c][s], c0, 0, 0, 0);
+            sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c][s], neg_m[c], 0, 0, 0);
           } else {
             sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c][s], sc[c][kb], 0, 0, 0);
           }
@@ -595,6 +596,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
         const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
         m_run[c] += delta;
         l_run[c] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) neg_m[c][r] = -m_run[c];
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
