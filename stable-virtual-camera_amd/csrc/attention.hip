@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_o[c][d][r] = 0.f;
   }
-  constexpr float RESCALE_THR = 8.0f;
+  constexpr float P_SUM_BOUND = 16384.0f;  // a lane's partial row sum at or above 2^14: look at the maximum, rescale (see the tile body)
 
   const int nt = (lk + KT - 1) / KT;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -579,19 +579,43 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
             if (key >= lk) sc[c][kb][r] = -1e30f;
           }
       }
-      float mk[KB];
+      // exp2 / pack / row sums FIRST, straight off the scores relative to m_run; the running maximum is looked at only when a
+      // partial row sum says a probability may have left the safe range (any P >= 2^14 makes its lane's sum >= 2^14; f16 holds
+      // 2^16 - 32 and cvt_pkrtz never rounds up), and on the first tile (m_run = 0 there: the true maximum protects the small
+      // probabilities from underflow).  The 21 v_max3 + the half-wave exchange per query block leave the steady-state loop.
+      float ls[4];
+      const auto exp_pack = [&]() {
+        ls[0] = ls[1] = ls[2] = ls[3] = 0.f;  // four partial sums: short dependent dot2 chains
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        mk[kb] = sc[c][kb][0];
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mk[kb] = fmaxf(mk[kb], sc[c][kb][r]);
-      }
-      float mx = mk[0];
+          for (int s2 = 0; s2 < 2; ++s2) {
+            fp16x2_t pk[4];
 #pragma unroll
-      for (int kb = 1; kb < KB; ++kb) mx = fmaxf(mx, mk[kb]);
-      mx = half_wave_max(mx);
+            for (int j = 0; j < 4; ++j) {
+              const float e0 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j]);
+              const float e1 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j + 1]);
+              pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+              ls[j] = __builtin_amdgcn_fdot2(pk[j], ones2, ls[j], false);
+            }
+            pf[c][kb][s2] = __builtin_bit_cast(half8_t, pk);
+          }
+        return (ls[0] + ls[1]) + (ls[2] + ls[3]);
+      };
+      float tot = exp_pack();
       const bool first = kt == 0;
-      if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {  // wave-uniform, rare
+      if (__builtin_expect(first || __any(!(tot < P_SUM_BOUND)), 0)) {  // wave-uniform, rare (NaN / inf sums land here too)
+        float mk[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          mk[kb] = sc[c][kb][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mk[kb] = fmaxf(mk[kb], sc[c][kb][r]);
+        }
+        float mx = mk[0];
+#pragma unroll
+        for (int kb = 1; kb < KB; ++kb) mx = fmaxf(mx, mk[kb]);
+        mx = half_wave_max(mx);
         const float delta = first ? mx : fmaxf(mx, 0.f);
         const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
         m_run[c] += delta;
@@ -606,23 +630,9 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[c][kb][r] -= delta;
+        tot = exp_pack();
       }
-      float ls[4] = {0.f, 0.f, 0.f, 0.f};  // four partial sums: short dependent dot2 chains
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          fp16x2_t pk[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float e0 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j]);
-            const float e1 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j + 1]);
-            pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
-            ls[j] = __builtin_amdgcn_fdot2(pk[j], ones2, ls[j], false);
-          }
-          pf[c][kb][s2] = __builtin_bit_cast(half8_t, pk);
-        }
-      l_run[c] += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+      l_run[c] += tot;
     }
     // ---- O^T += V^T P^T for both query blocks off ONE V^T fragment ----
     __builtin_amdgcn_s_setprio(1);
