@@ -75,6 +75,14 @@ class _VaeEngineBase:
                 pass  # subclass
             else:
                 conv3(p)
+        # channel-changing resnets: the 1x1 shortcut conv rides in the K loop of the second 3x3 conv (seva_gemm_desc.a2): one
+        # accumulation, and the shortcut result (fp32, up to 576 x 576 x 128 per frame) is neither written nor read back
+        self.fold_shortcut = _os.environ.get("SEVA_VAE_FOLD_SHORTCUT", "1") != "0"
+        for k in list(W):
+            if k.endswith(".conv_shortcut.w") and W[k].shape[1] % 64 == 0:
+                p = k[: -len(".conv_shortcut.w")]
+                W[p + ".conv2.wf"] = torch.cat([W[p + ".conv2.w"], W[k]], 1).contiguous()
+                W[p + ".conv2.bf"] = (W[p + ".conv2.b"] + W[p + ".conv_shortcut.b"]).contiguous()
         self.W = W
         self._pack_ends(sd, conv3)
 
@@ -100,28 +108,35 @@ class _VaeEngineBase:
         else:
             self._stats[out.data_ptr()] = st
 
-    def _resnet(self, p, x, n, h, w, cin, cout):
-        """diffusers ResnetBlock2D (no time embedding): GN-SiLU-conv-GN-SiLU-conv + shortcut."""
+    def _resnet(self, p, x, n, h, w, cin, cout, f16_out=None):
+        """diffusers ResnetBlock2D (no time embedding): GN-SiLU-conv-GN-SiLU-conv + shortcut.
+        f16_out: the block's only consumer is a resampling conv (A operand = f16): the second conv's epilogue rounds
+        `conv + shortcut` straight into that buffer -- the same rounding the separate cast pass made -- and the fp32 tensor
+        (4 B written, 4 B read back per element at up to 576 x 576 x 256) is never formed.  The shortcut conv's f16 input comes
+        out of the first GroupNorm's pass over x (`raw_f16`) instead of a cast pass of its own."""
         W, hw = self.W, h * w
         a16 = self._buf("gn16", (n, hw, cin), F16)
+        xs16 = self._buf("v_sk16", (n * hw, cin), F16) if cin != cout else None
         ops.groupnorm(x, None, W[p + ".norm1.g"], W[p + ".norm1.b"], a16, self.gn_ws, eps=1e-6, silu=True,
-                      stats1=self._stats.get(x.data_ptr()))
+                      stats1=self._stats.get(x.data_ptr()), raw_f16=None if xs16 is None else xs16.view(n, hw, cin))
         mid = self._buf("v_mid", (n, hw, cout), F32)
         st_mid = self._stats_buf("v_mid", n * hw, hw, cout)
         ops.conv3x3(a16.view(n, h, w, cin), W[p + ".conv1.w"], bias=W[p + ".conv1.b"], out_f32=mid, ch_stats=st_mid)
         b16 = self._buf("gn16", (n, hw, cout), F16)
         ops.groupnorm(mid, None, W[p + ".norm2.g"], W[p + ".norm2.b"], b16, self.gn_ws, eps=1e-6, silu=True, stats1=st_mid)
+        w2, b2, res, a2 = W[p + ".conv2.w"], W[p + ".conv2.b"], x, None
         if cin != cout:
-            xs16 = self._buf("v_sk16", (n * hw, cin), F16)
-            ops.cast_concat_f16(x, None, xs16)
-            res = self._buf("v_sk32", (n * hw, cout), F32)
-            ops.gemm(xs16, W[p + ".conv_shortcut.w"], bias=W[p + ".conv_shortcut.b"], out_f32=res)
-        else:
-            res = x
+            if self.fold_shortcut and (p + ".conv2.wf") in W:
+                w2, b2, res, a2 = W[p + ".conv2.wf"], W[p + ".conv2.bf"], None, xs16
+            else:
+                res = self._buf("v_sk32", (n * hw, cout), F32)
+                ops.gemm(xs16, W[p + ".conv_shortcut.w"], bias=W[p + ".conv_shortcut.b"], out_f32=res)
+        if f16_out is not None:
+            ops.conv3x3(b16.view(n, h, w, cout), w2, bias=b2, residual=res, a2=a2, out_f16=f16_out.view(n, hw, cout))
+            return f16_out
         out = self._buf("out:" + p, (n, hw, cout), F32)
         st_out = self._stats_buf("out:" + p, n * hw, hw, cout)
-        ops.conv3x3(b16.view(n, h, w, cout), W[p + ".conv2.w"], bias=W[p + ".conv2.b"], residual=res, out_f32=out,
-                    ch_stats=st_out)
+        ops.conv3x3(b16.view(n, h, w, cout), w2, bias=b2, residual=res, a2=a2, out_f32=out, ch_stats=st_out)
         self._produced(out, st_out)
         return out
 
@@ -194,13 +209,14 @@ class VaeDecoderEngine(_VaeEngineBase):
         rev = list(reversed(self.block_out))
         cin = rev[0]
         for i, cout in enumerate(rev):
+            up = i != len(rev) - 1
+            x16 = self._buf("v_up16", (n, h, w, cout), F16) if up else None
             for j in range(3):
-                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, n, h, w, cin if j == 0 else cout, cout)
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, n, h, w, cin if j == 0 else cout, cout,
+                                 f16_out=x16 if j == 2 else None)
             cin = cout
-            if i != len(rev) - 1:
+            if up:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                x16 = self._buf("v_up16", (n, h, w, cout), F16)
-                ops.cast_concat_f16(x, None, x16)
                 h, w = 2 * h, 2 * w
                 x = self._buf("out:" + p, (n, h * w, cout), F32)
                 st = self._stats_buf("out:" + p, n * h * w, h * w, cout)
@@ -253,13 +269,13 @@ class VaeEncoderEngine(_VaeEngineBase):
         self._produced(cur, st)
         cin = c0
         for i, cout in enumerate(self.block_out):
+            d16 = self._buf("v_dn16", (n, h, w, cout), F16) if i != nd else None
             for j in range(2):
-                cur = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", cur, n, h, w, cin if j == 0 else cout, cout)
+                cur = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", cur, n, h, w, cin if j == 0 else cout, cout,
+                                   f16_out=d16 if j == 1 else None)
             cin = cout
             if i != nd:
                 p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
-                d16 = self._buf("v_dn16", (n, h, w, cout), F16)
-                ops.cast_concat_f16(cur, None, d16)
                 h, w = h // 2, w // 2
                 cur = self._buf("out:" + p, (n, h * w, cout), F32)
                 st = self._stats_buf("out:" + p, n * h * w, h * w, cout)
