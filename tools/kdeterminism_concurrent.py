@@ -9,7 +9,8 @@ import torch
 from test_model_gpu import _build
 
 dev = torch.device("cuda:0")
-T, hw = 21, 16
+TAG = os.environ.get("MODEL", "tiny")   # MODEL=full HW=72: the 1.3 B network at the headline shape
+T, hw = int(os.environ.get("T", "21")), int(os.environ.get("HW", "16"))
 
 
 def inputs(seed):
@@ -25,7 +26,7 @@ stop = False
 def load():
     s2 = torch.cuda.Stream()
     with torch.cuda.stream(s2):
-        net, _ = _build("tiny", dev)
+        net, _ = _build(TAG, dev)
         eng = net.engine(); eng.use_graph = False
         x, concat, t, y, dense = inputs(11)
         while not stop:
@@ -33,7 +34,7 @@ def load():
             s2.synchronize()
 
 
-net, _ = _build("tiny", dev)
+net, _ = _build(TAG, dev)
 eng = net.engine(); eng.use_graph = False
 x, concat, t, y, dense = inputs(5)
 th = None
