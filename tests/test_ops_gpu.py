@@ -416,7 +416,9 @@ def test_attention_kv_split(dev, B, H, L, Lk, split, knobs):
 def test_attention_kernels_round_identically(dev, B, H, L, Lk, knobs):
     """attn_kernel (32 queries per wave) and the two-query-block kernel (64 per wave, shared K / V fragments) perform the same
     arithmetic in the same order per query row: their outputs are equal bit for bit, so which of them a launch gets (a rule on
-    lq) never shows in the result."""
+    lq) does not show in the result.  (Both take the first tile's maximum as the exponent reference; they differ only in WHEN a
+    later, rare rescale happens -- a score 8 above the reference in attn_kernel, a probability near 2^14 in attn2_kernel -- which
+    scores of this spread never reach; test_attention_prescaled_q[spike=True] covers those paths against fp64.)"""
     from seva import ops
     C = 64 * H
     g = torch.Generator().manual_seed(77)
