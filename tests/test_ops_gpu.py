@@ -412,6 +412,42 @@ def test_attention_kv_split(dev, B, H, L, Lk, split, knobs):
     assert not torch.equal(got, plain) or Lk < 128  # the split path really ran (a different association somewhere)
 
 
+@pytest.mark.parametrize("above", [12.0, 13.5, 14.2, 15.0, 15.9, 16.5, 18.0, 40.0])
+def test_attention_late_key_around_the_rescale_bound(dev, above):
+    """attn2_kernel exponentiates first and looks at the maximum only when a lane's partial row sum reaches 2^14: a late key whose
+    score lies `above` log2 units over the first tile's maximum walks that decision through every regime -- well below the bound
+    (P = 2^12, no rescale), just below / at / above it (2^13.5 ... 2^15.9: the sum test fires), beyond the f16 range (>= 2^16: the pack
+    saturates, the sum test fires) and far beyond (inf).  Every case must agree with fp64."""
+    from seva import ops
+    B, H, Lq, Lk = 1, 2, 2304, 320
+    C = 64 * H
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn((B, Lq, H, 64), generator=g)
+    k = torch.randn((B, Lk, H, 64), generator=g)
+    v = torch.randn((B, Lk, H, 64), generator=g)
+    qs = (q * QK_C).half()
+    # per (row, head) maximum over the first 64-key tile, in the kernel's own log2 units; the planted key (index 200) is the row's
+    # own direction scaled so that its score is that maximum + `above`
+    s0 = torch.einsum("blhd,bkhd->bhlk", qs.double(), k[:, :64].half().double()).amax(-1)          # [B, H, Lq]
+    # one key serves all rows: aim at row 0 of head 0 / 1; other rows see a smaller, harmless score
+    for h in range(H):
+        d = qs[0, 0, h].double()
+        k[0, 200, h] = (d / d.dot(d) * (float(s0[0, h, 0]) + above)).float()
+    q16, k16, v16 = qs.to(dev).view(B, Lq, C), k.half().to(dev).view(B, Lk, C), v.half().to(dev).view(B, Lk, C)
+    out = torch.full((B, Lq, C), float("nan"), device=dev, dtype=torch.float16)
+    ops.attention(q16, k16, v16, out, nb0=B, nb1=1, heads=H, lq=Lq, lk=Lk, q_strides=(Lq * C, 0, C), k_strides=(Lk * C, 0, C),
+                  o_strides=(Lq * C, 0, C), q_prescaled=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    qd = qs.double().transpose(1, 2)
+    kd, vd = k.half().double().transpose(1, 2), v.half().double().transpose(1, 2)
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) * math.log(2.0), -1) @ vd).transpose(1, 2).reshape(B, Lq, C)
+    err_all = rel_l2(out.cpu(), ref)
+    err_row0 = rel_l2(out[:, :1].cpu(), ref[:, :1])
+    print(f"\nlate key {above:4.1f} log2 units above the first tile's maximum: rel-L2 vs fp64 {err_all:.2e}, the targeted row {err_row0:.2e}")
+    assert err_all < 1e-3 and err_row0 < 2e-3
+
+
 @pytest.mark.parametrize("B,H,L,Lk", [(4, 5, 7000, 1100), (1, 10, 13500, 700), (3, 7, 6950, 640)])
 def test_attention_kernels_round_identically(dev, B, H, L, Lk, knobs):
     """attn_kernel (32 queries per wave) and the two-query-block kernel (64 per wave, shared K / V fragments) perform the same
