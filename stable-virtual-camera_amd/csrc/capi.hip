@@ -39,6 +39,7 @@ const KnobEntry kKnobs[] = {
     {"attn_no_tr", "SEVA_ATTN_NO_TR", &SevaKnobs::attn_no_tr}, {"attn_two", "SEVA_ATTN_TWO", &SevaKnobs::attn_two},
     {"attn_split", "SEVA_ATTN_SPLIT", &SevaKnobs::attn_split},
     {"gn_min_iter", "SEVA_GN_MIN_ITER", &SevaKnobs::gn_min_iter}, {"ff_variant", "SEVA_FF_VARIANT", &SevaKnobs::ff_variant},
+    {"conv_win", "SEVA_CONV_WIN", &SevaKnobs::conv_win},
 };
 SevaKnobs knobs_from_env() {
   SevaKnobs k;

@@ -1,0 +1,381 @@
+// 3x3 / stride 1 / pad 1 convolution as implicit GEMM with the INPUT WINDOW of the output tile staged in LDS
+// (reference: seva/modules/layers.py:101,113 -- the two 3x3 convs of every ResBlock; seva/model.py:57).
+//
+// gemm.hip's conv mode gathers one A tile per (tap, 64-channel slab): every input pixel of a tile crosses L2 -> LDS nine
+// times (PMC, round 3: 4.1x the algorithmic bytes), and the LDS-DMA stream is what bounds that main loop.  Here the
+// reduction runs slab-outer / tap-inner:
+//
+//   for each 64-channel slab s:   window = input pixels of the tile + halo, 128 B per pixel, staged ONCE
+//     for each tap (ky, kx):      A fragments = window rows shifted by ky * (W + 2) + kx;  weight tile (tap, s) streamed
+//
+// The window is a contiguous range of a PADDED pixel index space: every image row gets ONE frame cell in front (the right
+// frame of row r is the left frame of row r + 1), every image one frame row on top (the bottom frame of image i is the top
+// frame of image i + 1), images stacked: with Wp = W + 1 and S = (H + 1) Wp, output pixel m = (img, y, x) sits at
+// P(m) = img * S + (y + 1) Wp + (x + 1) and its tap (ky, kx) at P(m) + (ky - 1) Wp + (kx - 1), for every pixel of every image --
+// border taps land on frame cells, which the fill routes to the zero page.  A tile of BM consecutive output pixels needs
+// BM + (row crossings) + (W + 2 per image crossing) + 2 (W + 2) + 1 window pixels whatever its alignment, and the tap shift is
+// one workgroup-uniform scalar.  Tiles are consecutive pixels of the whole batch where that fits the window capacity (36x36
+// and smaller at 160 rows), consecutive pixels of ONE image otherwise (72x72).  Per slab and 160 x 160 tile the LDS-DMA traffic drops from
+// 9 * (160 + 160) * 128 B = 360 KiB to 316 * 128 B + 9 * 160 * 128 B = 220 KiB; the weight tile is now the main stream.
+//
+// Everything else is gemm.hip's core: K-tile 64, 128-byte LDS rows, lane-linear LDS-DMA with the chunk swizzle
+// (chunk c of row r at c ^ ((r >> 1) & 7)) applied on the per-lane SOURCE address and on the fragment reads, weight
+// fragment as the MFMA A operand (features on the lane), fp32 residual loaded straight into the accumulators, GroupNorm
+// statistics from the epilogue.  The window's swizzle key is the WINDOW pixel index, so a tap shift that is not a multiple
+// of 16 leaves some 2-way bank conflicts on the A fragment reads (measured: see DESIGN.md section 4).
+//
+// NW = 4: two workgroups per CU (the window single-buffered: 320 px + two 160-row weight stages = 80 KiB each).
+// NW = 8: one workgroup per CU on a 256-row tile, window double-buffered and refilled piece by piece under the taps.
+#include "gemm_common.h"
+
+#include <atomic>
+
+namespace {
+
+constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
+
+struct ConvWinGeom {
+  uint32_t mul_hw, mul_iw, mul_sp, mul_wp;  // floor(2^32 / d) + 1: x / d == mulhi(x, mul) for x * d < 2^32 (host-checked)
+  int32_t Wp, Sp, hw;
+  int32_t tiles_m, tiles_n;
+  int32_t tpi;  // 0: M-tiles are consecutive BM-pixel ranges of the whole batch; > 0: tiles per image (a tile never leaves its image)
+};
+
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS>
+__global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWinGeom g) {
+  constexpr int WMW = NW / 2, WNW = 2;
+  constexpr int WM = BM / WMW, WN = BN / WNW;  // per-wave tile
+  constexpr int MI = WM / 16, NJ = WN / 16;
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "per-wave tile must be whole MFMA blocks");
+  static_assert(!STATS || WM == 64, "statistics: a wave owns a 64-row block");
+  constexpr int NPC = WCAP / 8, PPW = (NPC + NW - 1) / NW;  // window pieces (8 pixels x 128 B), per wave
+  constexpr int NBP = BN / 8, BPW = (NBP + NW - 1) / NW;    // weight pieces per stage, per wave
+  constexpr int WIN_BYTES = WCAP * 128, B_BYTES = BN * 128;
+  constexpr int NWB = DBW ? 2 : 1;
+  static_assert(WCAP % 8 == 0, "window capacity in whole pieces");
+  static_assert(!DBW || PPW <= 8, "double-buffered window: one piece per wave and tap");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [window x NWB][weight stage 0][weight stage 1]
+  const char* const lds_win = smem;
+  const char* const lds_b = smem + NWB * WIN_BYTES;
+  const unsigned lds_base_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int sr = lane >> 3, sp = lane & 7;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  const int work = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = work / g.tiles_n, tn = work - tm * g.tiles_n;  // sibling N-tiles of an M-tile are neighbours on one XCD
+  // rows [m0, m_end) of the [M][N] output belong to this tile
+  uint32_t m0, m_end;
+  if (g.tpi > 0) {
+    const uint32_t img = (uint32_t)tm / (uint32_t)g.tpi, k = (uint32_t)tm - img * (uint32_t)g.tpi;
+    m0 = img * (uint32_t)g.hw + k * BM;
+    m_end = m0 + BM < (img + 1) * (uint32_t)g.hw ? m0 + BM : (img + 1) * (uint32_t)g.hw;
+  } else {
+    m0 = (uint32_t)tm * BM;
+    m_end = m0 + BM < (uint32_t)p.M ? m0 + BM : (uint32_t)p.M;
+  }
+  const int64_t n0 = (int64_t)tn * BN;
+
+  auto pad_index = [&](uint32_t m) -> uint32_t {
+    const uint32_t img = __umulhi(m, g.mul_hw);
+    const uint32_t rem = m - img * (uint32_t)g.hw;
+    const uint32_t y = __umulhi(rem, g.mul_iw);
+    const uint32_t x = rem - y * (uint32_t)p.iw;
+    return img * (uint32_t)g.Sp + (y + 1) * (uint32_t)g.Wp + x + 1;
+  };
+  const uint32_t P0 = pad_index(m0);
+  const uint32_t q0 = P0 - (uint32_t)(g.Wp + 1);                            // padded index of window pixel 0
+  const int WL = (int)(pad_index(m_end - 1) - P0) + 2 * (g.Wp + 1) + 1;     // window pixels this tile reads (<= WCAP)
+  const int npc = __builtin_amdgcn_readfirstlane((WL + 7) >> 3);
+
+  // ---- window fill: lane (pixel 8 pc + sr, physical chunk sp) of piece pc fetches logical chunk sp ^ key(pixel) ----
+  int woff[PPW];  // byte offset of the lane's 16 bytes in slab 0, or -1: frame pixel / past the batch -> zero page
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = i * NW + wave;
+    const int j = 8 * pc + sr;
+    const uint32_t q = q0 + (uint32_t)j;
+    const uint32_t img = __umulhi(q, g.mul_sp);
+    const uint32_t rem = q - img * (uint32_t)g.Sp;
+    const uint32_t py = __umulhi(rem, g.mul_wp);
+    const uint32_t px = rem - py * (uint32_t)g.Wp;
+    const bool ok = (img < (uint32_t)p.n) & (py >= 1u) & (px >= 1u) & (j < WL);  // row 0 / column 0 of an image block are frame cells
+    const int chunk = sp ^ ((j >> 1) & 7);
+    const uint32_t pix = (img * (uint32_t)p.ih + (py - 1)) * (uint32_t)p.iw + (px - 1);
+    woff[i] = ok ? (int)((pix * (uint32_t)p.cin + (uint32_t)chunk * 8u) * 2u) : -1;
+  }
+  auto fill_piece = [&](int i, int s, int wb) {  // i: compile-time after unrolling
+    const int pc = i * NW + wave;
+    if (pc < npc) {  // wave-uniform
+      const char* const src = woff[i] >= 0 ? (const char*)p.a + (int64_t)s * 128 + woff[i] : (const char*)g_zero_page;
+      glds16_raw(src, lds_base_u32 + wb * WIN_BYTES + pc * 1024);
+    }
+  };
+  auto fill_window = [&](int s, int wb) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) fill_piece(i, s, wb);
+  };
+
+  // ---- weight stage: BN rows x 128 B of K-tile (tap t, slab s) = columns t * cin + 64 s ----
+  const half_t* b_ptr[BPW];
+#pragma unroll
+  for (int i = 0; i < BPW; ++i) {
+    const int row = 8 * (i * NW + wave) + sr;
+    const int q = sp ^ ((row >> 1) & 7);
+    int64_t n = n0 + row;
+    if (n >= p.N) n = p.N - 1;
+    b_ptr[i] = p.w + n * p.K + q * 8;
+  }
+  auto stage_w = [&](int buf, int kcol) {
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+      const int pc = i * NW + wave;
+      if (NBP % NW == 0 || pc < NBP) glds16_raw(b_ptr[i] + kcol, lds_base_u32 + NWB * WIN_BYTES + buf * B_BYTES + pc * 1024);
+    }
+  };
+
+  // ---- fragment addresses ----
+  int b_off[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int rb = wn * WN + fr;
+    b_off[s2] = rb * 128 + (((4 * s2 + fg) ^ ((rb >> 1) & 7)) << 4);
+  }
+  int a_base[MI];  // window pixel of (row 16 i + fr of the wave's tile) at tap (0, 0)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    uint32_t m = m0 + wm * WM + 16 * i + fr;
+    if (m >= m_end) m = m_end - 1;
+    a_base[i] = (int)(pad_index(m) - P0);
+  }
+
+  const int nslab = p.cin / BK;
+  fill_window(0, 0);
+  stage_w(0, 0);
+
+  f32x4 acc[MI][NJ];
+  if (p.residual) {  // the residual tile goes straight into the accumulators (clamped addresses; stores are guarded)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      int64_t m = (int64_t)m0 + wm * WM + 16 * i + fr;
+      if (m >= m_end) m = m_end - 1;
+      const float* rp = p.residual + m * p.ldr;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+        if (f > p.N - 4) f = p.N - 4;
+        acc[i][j] = *(const f32x4*)(rp + f);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // retire the residual loads for hipcc's wait bookkeeping HERE: a load still "possibly pending" at the loop header gets a literal
+  // vmcnt in front of its first use in every iteration, and that literal would also drain the LDS-DMA the compiler cannot see
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
+
+  int gk = 0;  // running K-tile index (parity = weight stage)
+  for (int s = 0; s < nslab; ++s) {
+    const char* const win = lds_win + (DBW ? (s & 1) * WIN_BYTES : 0);
+    const bool more = s + 1 < nslab;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int cur = gk & 1;
+      ++gk;
+      if (t < 8) stage_w(cur ^ 1, (t + 1) * p.cin + BK * s);
+      else if (more) stage_w(cur ^ 1, BK * (s + 1));
+      if constexpr (DBW) {  // the next slab's window, one piece per wave and tap, into the other buffer
+        if (more && t < PPW) fill_piece(t, s + 1, (s + 1) & 1);
+      }
+      const char* const tb = lds_b + cur * B_BYTES;
+      int toff = (t / 3) * g.Wp + (t % 3);
+      asm volatile("" : "+s"(toff));  // opaque: the nine taps' fragment addresses are formed here, not hoisted out of the slab loop (45 registers)
+      half8_t af[2][MI], bf[2][NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int j = a_base[i] + toff;
+        const int addr = j * 128 + ((fg ^ ((j >> 1) & 7)) << 4);
+        af[0][i] = *(const half8_t*)(win + addr);
+        af[1][i] = *(const half8_t*)(win + (addr ^ 64));
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[s2][j] = *(const half8_t*)(tb + b_off[s2] + j * 2048);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+      if constexpr (!DBW) {
+        if (t == 8 && more) {  // every wave has read the last tap's fragments: the window is free for the next slab
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          fill_window(s + 1, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+
+  // ---- epilogue (gemm.hip's plain one): lane holds features f .. f+3 (rows of D) of pixel m (column of D) ----
+  f32x4 bj[NJ];
+  int fj[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+    if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
+    fj[j] = (int)f;
+    bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t m = (int64_t)m0 + wm * WM + 16 * i + fr;
+    const int64_t mc = m < m_end ? m : m_end - 1;
+    f32x4 v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j] = acc[i][j] + bj[j];
+    if (p.row_add) {
+      const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = v[j];  // the statistics pass reads the final values
+    }
+    const bool row_ok = m < m_end;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+      if (!row_ok || f >= p.N) continue;
+      if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v[j];
+      if (p.out_f16) {
+        half4_t h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
+        *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
+      }
+    }
+  }
+  if constexpr (STATS) {
+    if (p.ch_stats != nullptr) {  // per 64-row block and channel: sum and sum of squares (gemm.hip, same association)
+      const int64_t mw = (int64_t)m0 + wm * WM;
+      float* const sp_ = p.ch_stats + (mw >> 6) * 2 * p.N;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, qsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const f32x4 vm = mw + 16 * i + fr < m_end ? acc[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the tile contribute nothing
+          ssum += vm;
+          qsum += vm * acc[i][j];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ssum[r] = row16_sum(ssum[r]);
+          qsum[r] = row16_sum(qsum[r]);
+        }
+        const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
+        if (fr == 0 && mw < m_end && f < p.N) {
+          *(f32x4*)(sp_ + f) = ssum;
+          *(f32x4*)(sp_ + p.N + f) = qsum;
+        }
+      }
+    }
+  }
+}
+
+uint32_t magic_u32(uint32_t d) { return (uint32_t)(0x100000000ull / d) + 1u; }
+
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS>
+int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
+  constexpr int lds = (DBW ? 2 : 1) * WCAP * 128 + 2 * BN * 128;
+  static std::atomic<uint64_t> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t dev_bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
+    (void)hipFuncSetAttribute((const void*)conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_devs.fetch_or(dev_bit, std::memory_order_relaxed);
+  }
+  ConvWinGeom g = g0;
+  g.tiles_n = (int)((a.N + BN - 1) / BN);
+  // the widest window any tile needs must fit the instantiation's capacity: consecutive pixels of the whole batch if that fits
+  // (a tile may then straddle images), else consecutive pixels of one image, else the launch is not for this kernel
+  const auto pad_index = [&](int64_t m) {
+    const int64_t img = m / g.hw, rem = m % g.hw;
+    return img * g.Sp + (rem / a.iw + 1) * g.Wp + rem % a.iw + 1;
+  };
+  const auto widest = [&](int tpi) {
+    const int64_t tiles = tpi > 0 ? (int64_t)tpi : (a.M + BM - 1) / BM;  // per-image tiling: every image has the same windows
+    int64_t wl_max = 0;
+    for (int64_t t = 0; t < tiles; ++t) {
+      const int64_t lim = tpi > 0 ? g.hw : a.M;
+      const int64_t ma = t * BM, mb = ma + BM < lim ? ma + BM : lim;
+      const int64_t wl = pad_index(mb - 1) - pad_index(ma) + 2 * (g.Wp + 1) + 1;
+      if (wl > wl_max) wl_max = wl;
+    }
+    return wl_max;
+  };
+  const int tpi = (g.hw + BM - 1) / BM;
+  if (widest(0) <= WCAP) {
+    g.tpi = 0;
+    g.tiles_m = (int)((a.M + BM - 1) / BM);
+  } else if (widest(tpi) <= WCAP && !(a.ch_stats != nullptr && g.hw % 64 != 0)) {  // (statistics: 64-row blocks of the WHOLE tensor)
+    g.tpi = tpi;
+    g.tiles_m = a.n * tpi;
+  } else {
+    return 1;  // not applicable: the caller falls back to the per-tap gather
+  }
+  const int64_t nb = (int64_t)g.tiles_m * g.tiles_n;
+  if (nb <= 0 || nb > 0x7fffffff) {
+    seva_set_error("conv_win: bad grid %lld", (long long)nb);
+    return SEVA_ERR_ARG;
+  }
+  hipLaunchKernelGGL((conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS>), dim3((unsigned)nb), dim3(64 * NW), lds, s, a, g);
+  return seva_check_launch("conv_win_kernel");
+}
+
+}  // namespace
+
+// 0 = launched, 1 = not applicable (the caller uses the per-tap gather of gemm.hip), < 0 = error
+int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
+  const int knob = g_seva_knobs.conv_win;
+  if (knob == 0) return 1;
+  if (a.stride != 1 || a.upsample || a.pad_lo != 1 || a.a2 != nullptr || a.sk_ws != nullptr) return 1;
+  if (a.oh != a.ih || a.ow != a.iw || a.iw < 2 || a.ih < 2) return 1;
+  if (a.cin % 64 != 0 || a.N % 160 != 0 || a.K != 9LL * a.cin) return 1;
+  ConvWinGeom g{};
+  g.Wp = a.iw + 1;
+  g.Sp = (a.ih + 1) * g.Wp;
+  g.hw = a.ih * a.iw;
+  // exactness of the multiply-high divisions (x * d < 2^32) and 31-bit byte offsets into the image
+  const uint64_t q_max = (uint64_t)a.n * g.Sp + 1024;
+  if (q_max * (uint64_t)g.Sp >= (1ull << 32) || (uint64_t)a.M * (uint64_t)g.hw >= (1ull << 32)) return 1;
+  if ((uint64_t)a.n * g.hw * a.cin * 2 >= (1ull << 31)) return 1;
+  g.mul_hw = magic_u32((uint32_t)g.hw);
+  g.mul_iw = magic_u32((uint32_t)a.iw);
+  g.mul_sp = magic_u32((uint32_t)g.Sp);
+  g.mul_wp = magic_u32((uint32_t)g.Wp);
+  const bool stats = a.ch_stats != nullptr;
+  if (knob == 2) return launch_win<256, 160, 8, 416, true, true>(a, g, s);
+  if (stats) return launch_win<128, 160, 4, 288, false, true>(a, g, s);
+  return launch_win<160, 160, 4, 320, false, false>(a, g, s);
+}

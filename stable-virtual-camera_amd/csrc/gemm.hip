@@ -65,18 +65,6 @@ __device__ __forceinline__ f32x4 mfma_f8(int j, half8_t w_lo, half8_t w_hi, half
   }
 }
 
-// sum over the 16 lanes of a DPP row, result in every lane (row_ror 8, 4, 2, 1: a fixed association)
-__device__ __forceinline__ float row16_sum(float v) {
-#define SEVA_ROR_ADD(N)                                                                                              \
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false))
-  SEVA_ROR_ADD(8);
-  SEVA_ROR_ADD(4);
-  SEVA_ROR_ADD(2);
-  SEVA_ROR_ADD(1);
-#undef SEVA_ROR_ADD
-  return v;
-}
-
 // NW: waves per workgroup.  4 (2 x 2 wave tiles, two workgroups per CU) everywhere in production; the experimental library also
 // instantiates 8 (2 x 4 wave tiles, ONE workgroup per CU): two N-sibling 128 x 160 tiles fused so that their A rows are staged once
 // (128 x 320: 0.0109 operand bytes per FLOP; same per-wave tile, registers and waves per SIMD as 128 x 160) -- measured slower.
@@ -1135,6 +1123,13 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
       a.sk_ws = d->splitk_ws;
       half_m = false;
     }
+  }
+  // 3x3 / stride 1 / pad 1 convs whose tile window fits LDS: the input window (+ halo) is staged once per 64-channel slab and the nine
+  // taps read it through shifted fragment addresses (conv_win.hip); everything else keeps the per-tap gather below
+  if (d->mode == 1 && !two_src && !narrow && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0 && g_seva_knobs.gemm_bm <= 0 &&
+      g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0) {
+    const int rc = seva_conv_win_launch(a, s);
+    if (rc <= 0) return rc;
   }
   if (d->epilogue == 1) {
     // GEGLU tiles are 128 wide (the epilogue pairs 64-row value / gate groups), so the cheaper operand stream comes from the

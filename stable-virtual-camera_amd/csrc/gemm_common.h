@@ -97,6 +97,21 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   return start + (bid >> 3);
 }
 
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror 8, 4, 2, 1: a fixed association)
+static __device__ __forceinline__ float row16_sum(float v) {
+#define SEVA_ROR_ADD(N)                                                                                              \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false))
+  SEVA_ROR_ADD(8);
+  SEVA_ROR_ADD(4);
+  SEVA_ROR_ADD(2);
+  SEVA_ROR_ADD(1);
+#undef SEVA_ROR_ADD
+  return v;
+}
+
+// conv_win.hip: 3x3 / stride 1 / pad 1 conv with the tile's input window staged in LDS.  0 = launched, 1 = not applicable, < 0 = error
+int seva_conv_win_launch(const GemmArgs& a, hipStream_t s);
+
 // gemm_sk.hip: stream-K variant of the plain f32-output kernel (a.tiles_m / a.tiles_n for 128 x bn tiles, a.sk_ws set)
 int seva_gemm_streamk_launch(const GemmArgs& a, int mode, int bn, int nblocks, hipStream_t s);
 // gemm_ring.hip: cfg 1 = 256x128x64 (3 stages), cfg 2 = 256x256x32 (4 stages), cfg 3 = 128x128x32 (4 stages)

@@ -36,6 +36,7 @@ struct SevaKnobs {
   int attn_dbg, attn_no_tr, attn_two, attn_split;
   int gn_min_iter;
   int ff_variant;
+  int conv_win;  // 0: per-tap gather everywhere; 1: window kernel, two 4-wave workgroups per CU; 2: 8-wave 256-row tile; unset: default
 };
 extern SevaKnobs g_seva_knobs;
 
