@@ -443,47 +443,69 @@ def main():
         "cond_assembly": {"ms": cond_assembly_ms,
                           "what": "camera normalisation (host) + Pluecker maps + cond/uc assembly (HIP), once per window, outside `value`; median of 3"},
     }
-    printed = threading.Lock()
+    print_lock = threading.Lock()
+    state = {"printed": False, "leg": "none"}
 
     def emit():
-        if printed.acquire(blocking=False) and rank == 0:
-            print(json.dumps(out), flush=True)
+        # the lock is held across print AND flush: a watchdog firing while the main thread is inside emit() waits for the
+        # whole line instead of cutting it, and the line is printed exactly once
+        with print_lock:
+            if not state["printed"] and rank == 0:
+                print(json.dumps(out), flush=True)
+            state["printed"] = True
 
     def watchdog():
-        out["legs_cut_short"] = f"an auxiliary leg did not finish within {leg_limit:.0f} s; the line is printed without it"
+        # a hung auxiliary leg (e.g. a collective some rank never reaches): the headline line is printed as it stands, the leg
+        # that was running is named, and the process ends NON-ZERO on every rank -- a hang is not reported as success
+        out["legs_cut_short"] = (f"auxiliary leg '{state['leg']}' did not finish within {leg_limit:.0f} s; the line is printed "
+                                 "without it and the process exits with code 3")
         emit()
-        os._exit(0)
+        os._exit(3)
 
     leg_limit = float(os.environ.get("SEVA_BENCH_LEG_TIMEOUT", "900"))
     timer = threading.Timer(leg_limit, watchdog)
     timer.daemon = True
     timer.start()
 
-    def leg(fn, *a):
+    def leg(name, fn, *a):
+        state["leg"] = name
         try:
             return fn(*a)
         except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
             return {"error": f"{type(e).__name__}: {e}"[:400]}
 
-    if not args.no_other_configs and (T, hw) == (21, 72) and args.precision == "f16":
-        if world == 1:
-            # BASELINE configs 2, 3, 5 and (on this one GPU) 4 -- outside `value`
-            other = {"config2_T8": leg(steps_leg, net, device, 8, hw, args.other_steps),
-                     "config3_T24_one_window": leg(steps_leg, net, device, 24, hw, args.other_steps)}
-            net.set_precision("fp8")
-            r8 = leg(steps_leg, net, device, T, hw, args.other_steps)
+    def fp8_leg():
+        net.set_precision("fp8")
+        try:
+            r8 = steps_leg(net, device, T, hw, args.other_steps)
             r8["dtype"] = "f8e4m3 (C>=640 levels) + f16 (C=320 level); separate accuracy class, not the parity mode"
-            other["config5_fp8_T21"] = r8
+            return r8
+        finally:
             net.set_precision("f16")
-            other["config4_trajectory168_one_gpu"] = leg(trajectory_leg, net, device, rank, world, 168, hw, T, args.leg_traj_steps, False)
-            out["other_configs"] = other
-        else:
-            out["trajectory"] = leg(trajectory_leg, net, device, rank, world, 168, hw, T, args.leg_traj_steps, True)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = leg(cpu_baseline, sd)
-    timer.cancel()
-    emit()
+    # whatever happens below -- an exception outside a leg included -- the headline line is printed
+    try:
+        if not args.no_other_configs and (T, hw) == (21, 72) and args.precision == "f16":
+            if world == 1:
+                # BASELINE configs 2, 3, 5 and (on this one GPU) 4 -- outside `value`
+                other = {"config2_T8": leg("config2_T8", steps_leg, net, device, 8, hw, args.other_steps),
+                         "config3_T24_one_window": leg("config3_T24", steps_leg, net, device, 24, hw, args.other_steps),
+                         "config5_fp8_T21": leg("config5_fp8", fp8_leg)}
+                other["config4_trajectory168_one_gpu"] = leg("config4_trajectory", trajectory_leg, net, device, rank, world, 168, hw, T,
+                                                             args.leg_traj_steps, False)
+                out["other_configs"] = other
+            else:
+                out["trajectory"] = leg("trajectory", trajectory_leg, net, device, rank, world, 168, hw, T, args.leg_traj_steps, True)
+
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = leg("cpu_baseline", cpu_baseline, sd)
+        state["leg"] = "none"
+    except BaseException as e:  # noqa: BLE001
+        out["legs_error"] = f"{type(e).__name__}: {e}"[:400]
+        raise
+    finally:
+        timer.cancel()
+        emit()
     if world > 1:
         dist.barrier()  # rank 0 alone ran the VAE / CPU legs: nobody tears the communicator down under it
         dist.destroy_process_group()

@@ -96,19 +96,10 @@ typedef struct seva_gemm_desc {
    * one 128 x BN fp32 tile per output tile: splitk_ws_bytes >= 4 * (16384 + max(tiles, 512) * 128 * 160) (512 slots serve the
    * opt-in stream-K kernel, knob gemm_streamk = 1, which fp32-output GEMMs and convs of >= 512 tiles then use).  The hand-off
    * uses agent-scope (sc1) stores / loads, no cache-wide fence.  One launch at a time may
-   * use a given workspace (launches on ONE stream are fine). */
+   * use a given workspace (launches on ONE stream are fine).  A workspace too small for a launch that qualifies for the split is
+   * an ERROR (ABI 8; it was a silent fall-back to the unsplit kernel): whether a sample is split never depends on the batch. */
   float* splitk_ws;
   int64_t splitk_ws_bytes;
-  /* optional LayerNorm prologue (ABI 7; reference transformer.py:102-104 `attn1(norm1(x))`): when ln_x is set, `a` is ignored and
-   * the A operand is LayerNorm(ln_x) * ln_gamma + ln_beta over the K columns of the fp32 rows ln_x[M][ldx], normalised in
-   * registers by the A-in-registers kernel (exact two-pass statistics, one f16 rounding: what the LayerNorm kernel's output
-   * had).  Plain mode and epilogue, K <= 320 (K % 64 == 0), f16-only output: the fused QKV projection of the C = 320 level --
-   * its standalone LayerNorm launch and the 139 MB f16 tensor between the two disappear. */
-  const float* ln_x;
-  const float* ln_gamma;
-  const float* ln_beta;
-  int64_t ldx;
-  float ln_eps;
   /* optional second A operand of a 3x3 convolution (ABI 7; mode 1, no upsample): a2 [M][lda2] f16 whose K2 columns (K2 % 64 == 0)
    * FOLLOW the nine taps in the reduction, K = 9 * cin + K2 and w = [w_conv | w_2] per output row.  Folds the ResBlock's 1x1
    * skip convolution (seva/modules/layers.py:137-139: `skip_connection(x) + h`) into its second 3x3 conv: one accumulation, no

@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p, int64_t r
       const float w = __builtin_amdgcn_exp2f(m[s] - mx);
       lt += w * l[s];
       const float* po = p.part_o + ((int64_t)s * rows_all + row) * 64 + 8 * ch;
-      const f32x4 a = *(const f32x4*)po, b = *(const f32x4*)(po + 4);
+      const f32x4 a = first_read(*(const f32x4*)po), b = first_read(*(const f32x4*)(po + 4));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         o[r] += w * a[r];

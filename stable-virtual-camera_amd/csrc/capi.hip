@@ -89,7 +89,7 @@ SevaProfScope::~SevaProfScope() {
 extern "C" {
 
 const char* seva_last_error(void) { return g_err; }
-int seva_abi_version(void) { return 7; }
+int seva_abi_version(void) { return 8; }
 const char* seva_target_arch(void) { return "gfx950"; }
 
 int seva_set_knob(const char* name, int value) {

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
     int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
     if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
     fj[j] = (int)f;
-    bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bj[j] = p.bias ? first_read(*(const f32x4*)(p.bias + f)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
     if (p.row_add) {
       const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
+      for (int j = 0; j < NJ; ++j) v[j] += first_read(*(const f32x4*)(rp + fj[j]));
     }
     if constexpr (STATS) {
 #pragma unroll
@@ -375,7 +375,26 @@ int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
   g.mul_sp = magic_u32((uint32_t)g.Sp);
   g.mul_wp = magic_u32((uint32_t)g.Wp);
   const bool stats = a.ch_stats != nullptr;
-  if (knob == 2) return launch_win<256, 160, 8, 416, true, true>(a, g, s);
-  if (stats) return launch_win<128, 160, 4, 288, false, true>(a, g, s);
-  return launch_win<160, 160, 4, 320, false, false>(a, g, s);
+  // Two instantiation families, bitwise equal to each other (same reduction order): two 4-wave workgroups per CU on 160-row tiles
+  // (128 with statistics) or one 8-wave workgroup on a 256-row tile with the window double-buffered.  The 8-wave tile moves a third
+  // fewer LDS-DMA bytes per FLOP and is ~5 % faster where its tile count fills whole rounds of the 256 CUs; the choice is made from
+  // how the launch quantises (measured: 72x72 and 18x18 at batch 42 prefer 8 waves, 36x36 prefers 4: tools/kconvwin.py).  Which of
+  // the two RUNS may depend on the batch; whether the window kernel runs at all depends on per-sample dimensions only.
+  const auto launch4 = [&]() { return stats ? launch_win<128, 160, 4, 288, false, true>(a, g, s) : launch_win<160, 160, 4, 320, false, false>(a, g, s); };
+  const auto launch8 = [&]() { return launch_win<256, 160, 8, 416, true, true>(a, g, s); };
+  bool eight;
+  if (knob == 1 || knob == 2) {
+    eight = knob == 2;
+  } else {
+    const double tn = (double)((a.N + 159) / 160);
+    const double t8 = (double)((a.M + 255) / 256) * tn, t4 = (double)((a.M + (stats ? 127 : 159)) / (stats ? 128 : 160)) * tn;
+    const double r8 = t8 / 256.0, r4 = t4 / 512.0;
+    const double f4 = r4 - (double)(int64_t)r4;
+    const double tail4 = f4 > 0.0 ? (f4 <= 0.5 ? 0.55 : 0.55 + 0.9 * (f4 - 0.5)) : 0.0;  // a partly filled round of 4-wave workgroups runs one per CU
+    const double cost8 = 0.95 * (double)(int64_t)(r8 + 0.999999) / r8, cost4 = ((double)(int64_t)r4 + tail4) / r4;
+    eight = t8 >= 256.0 && cost8 < cost4;
+  }
+  int rc = eight ? launch8() : launch4();
+  if (rc == 1) rc = eight ? launch4() : launch8();  // the other family may still fit (window capacity is per family)
+  return rc;
 }

@@ -123,7 +123,7 @@ __global__ void add_f32_kernel(const float* __restrict__ a, const float* __restr
                                float* __restrict__ out, int64_t count4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4;
        i += (int64_t)gridDim.x * blockDim.x)
-    ((f32x4*)out)[i] = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+    ((f32x4*)out)[i] = first_read(((const f32x4*)a)[i]) + first_read(((const f32x4*)b)[i]);
 }
 
 __global__ void replace_blend_kernel(const float* __restrict__ x, const float* __restrict__ rep,

@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FfArgs p) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const float* bp = lds_b1 + hc * 128 + 64 * q + 8 * fg + 4 * e;
-        b1v[q][e] = *(const f32x4*)bp;
-        b1g[q][e] = *(const f32x4*)(bp + 32);
+        b1v[q][e] = first_read(*(const f32x4*)bp);
+        b1g[q][e] = first_read(*(const f32x4*)(bp + 32));
       }
 
     half8_t hfrag[2][2];  // [token block i][32-feature group q]: features 32q + 8fg .. +7 of the chunk
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FfArgs p) {
 #pragma unroll
     for (int jb = 0; jb < NJ2; ++jb) {
       const int f = 16 * jb + 4 * fg;
-      const f32x4 v = acc2[i][jb] + *(const f32x4*)(p.b2 + f);
+      const f32x4 v = acc2[i][jb] + first_read(*(const f32x4*)(p.b2 + f));
       if (!ok) continue;
       if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v;
       if (p.out_f16) {
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
       f32x4 v[KS][2];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        v[ks][0] = *(const f32x4*)(xr + 32 * ks);
-        v[ks][1] = *(const f32x4*)(xr + 32 * ks + 4);
+        v[ks][0] = first_read(*(const f32x4*)(xr + 32 * ks));
+        v[ks][1] = first_read(*(const f32x4*)(xr + 32 * ks + 4));
       }
       float sum = 0.f;
 #pragma unroll
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
         half_t y[8];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const f32x4 g4 = *(const f32x4*)(p.ln_gamma + 32 * ks + 8 * fg + 4 * e);
-          const f32x4 b4 = *(const f32x4*)(p.ln_beta + 32 * ks + 8 * fg + 4 * e);
+          const f32x4 g4 = first_read(*(const f32x4*)(p.ln_gamma + 32 * ks + 8 * fg + 4 * e));
+          const f32x4 b4 = first_read(*(const f32x4*)(p.ln_beta + 32 * ks + 8 * fg + 4 * e));
 #pragma unroll
           for (int r = 0; r < 4; ++r) y[4 * e + r] = (half_t)((v[ks][e][r] - mean) * rstd * g4[r] + b4[r]);
         }
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
 #pragma unroll
     for (int jj = 0; jj < NJH; ++jj) {
       const int f = 16 * (h * NJH + jj) + 4 * fg;
-      const f32x4 v = acc2[i][jj] + *(const f32x4*)(p.b2 + f);
+      const f32x4 v = acc2[i][jj] + first_read(*(const f32x4*)(p.b2 + f));
       if (!ok) continue;
       if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v;
       if (p.out_f16) {

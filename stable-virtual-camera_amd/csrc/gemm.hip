@@ -68,10 +68,8 @@ __device__ __forceinline__ f32x4 mfma_f8(int j, half8_t w_lo, half8_t w_hi, half
 // NW: waves per workgroup.  4 (2 x 2 wave tiles, two workgroups per CU) everywhere in production; the experimental library also
 // instantiates 8 (2 x 4 wave tiles, ONE workgroup per CU): two N-sibling 128 x 160 tiles fused so that their A rows are staged once
 // (128 x 320: 0.0109 operand bytes per FLOP; same per-wave tile, registers and waves per SIMD as 128 x 160) -- measured slower.
-// LNP (ASTAT, plain epilogue only): the A panel is LayerNorm(ln_x), normalised in registers (seva_gemm_desc.ln_x) -- its own instantiation
-template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false, bool SPLITK = false, int NW = 4, bool LNP = false>
+template <int BM, int BN, int MODE, int EPI, bool DBGK, bool PAIRED, bool ASTAT, bool FP8 = false, bool SPLITK = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
-  static_assert(!LNP || (ASTAT && !FP8 && EPI == 0), "LayerNorm prologue: A-in-registers kernel, plain epilogue");
   const int dbg = DBGK ? p.dbg : 0;
   static_assert(NW == 4 || (NW == 8 && !DBGK && !PAIRED && !ASTAT && !FP8 && !SPLITK), "8 waves: plain fp32-output kernels only");
   constexpr int WNW = NW / 2;  // waves along N
@@ -357,63 +355,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   // row fr, k = 32*ks + 8*fg .. +7), then retired for hipcc's wait-count bookkeeping before the loop
   half8_t areg[ASTAT ? MI : 1][ASTAT ? KS_A : 1];
   if constexpr (ASTAT) {
-    if constexpr (LNP) {
-      // LayerNorm prologue (seva_gemm_desc.ln_x; reference transformer.py:102-104): the wave's 32 rows are read as fp32; a row
-      // lives in the 4 lanes (fr, fg = 0..3) that hold its k = 32 ks + 8 fg + j, so the exact two-pass statistics cost two
-      // xor-shuffles each; the normalised row goes straight into the A fragments (one f16 rounding, as the LayerNorm kernel's
-      // output had).  16 rows at a time: 80 transient registers.
-      const int nks = (int)(p.K / 32);
-      const float inv_c = 1.0f / (float)p.K;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        int64_t m = m0 + wm * WM + 16 * i + fr;
-        if (m >= p.M) m = p.M - 1;
-        const float* xr = p.ln_x + m * p.ldx + 8 * fg;
-        f32x4 v[KS_A][2];
-#pragma unroll
-        for (int ks = 0; ks < KS_A; ++ks) {
-          const int kk = ks < nks ? 32 * ks : 0;  // K < 320: unused k-steps re-read column 0 (never used)
-          v[ks][0] = *(const f32x4*)(xr + kk);
-          v[ks][1] = *(const f32x4*)(xr + kk + 4);
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS_A; ++ks)
-          if (ks < nks) sum += (v[ks][0][0] + v[ks][0][1] + v[ks][0][2] + v[ks][0][3]) + (v[ks][1][0] + v[ks][1][1] + v[ks][1][2] + v[ks][1][3]);
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * inv_c;
-        float ss = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS_A; ++ks)
-          if (ks < nks) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float dlt = v[ks][e][r] - mean;
-                ss += dlt * dlt;
-              }
-          }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float rstd = rsqrtf(ss * inv_c + p.ln_eps);
-#pragma unroll
-        for (int ks = 0; ks < KS_A; ++ks) {
-          const int kk = ks < nks ? 32 * ks : 0;
-          half_t y[8];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const f32x4 g4 = *(const f32x4*)(p.ln_gamma + kk + 8 * fg + 4 * e);
-            const f32x4 b4 = *(const f32x4*)(p.ln_beta + kk + 8 * fg + 4 * e);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[4 * e + r] = (half_t)((v[ks][e][r] - mean) * rstd * g4[r] + b4[r]);
-          }
-          areg[i][ks] = half8_t{y[0], y[1], y[2], y[3], y[4], y[5], y[6], y[7]};
-        }
-        asm volatile("" ::: "memory");  // one 16-row group at a time: the next group's 20 loads are not hoisted above this one's math
-      }
-    } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       int64_t m = m0 + wm * WM + 16 * i + fr;
@@ -424,7 +365,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
         const int kk = 32 * ks < (int)p.K ? 32 * ks : 0;  // K < 320: unused k-steps re-read column 0
         areg[i][ks] = *(const half8_t*)(ap + kk);
       }
-    }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -602,7 +542,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
       for (int j = 0; j < NB; ++j) {
         const int idx = EPI == 0 ? wn * WN + feat_of(j, fg)
                                  : wn * WN + 64 * (j >> 2) + 8 * fg + 4 * (j & 1) + 32 * ((j >> 1) & 1);
-        bias_r[j] = p.bias ? *(const f32x4*)(bias_slot + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias_r[j] = p.bias ? first_read(*(const f32x4*)(bias_slot + idx * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -612,12 +552,12 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
     };
     auto bias_at = [&](int j) -> f32x4 {
       if (!p.bias) return f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ASTAT) return *(const f32x4*)(bias_cur + bias_idx(j) * 4);
+      if (ASTAT) return first_read(*(const f32x4*)(bias_cur + bias_idx(j) * 4));
       if (ASYNC) return bias_r[j];
       // staged-A debug build: straight from global memory (GEGLU rows: value at +0, gate at +32 of each 64)
       int64_t f = n0 + bias_idx(j);
       if (f > p.N - 4) f = p.N - 4;
-      return *(const f32x4*)(p.bias + f);
+      return first_read(*(const f32x4*)(p.bias + f));
     };
     // both LDS buffers are free: start the next tile's first stage(s) before the epilogue
     if (tn + 1 < tn_end) {
@@ -663,7 +603,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) pt[j] = ld_coherent_x4(part + (i * NJ + j) * 1024);
+            for (int j = 0; j < NJ; ++j) pt[j] = first_read(ld_coherent_x4(part + (i * NJ + j) * 1024));
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] += pt[j];
           }
@@ -700,8 +640,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
             int64_t f0 = f, f1 = f + 4;
             if (f0 > p.N - 4) f0 = p.N - 4;
             if (f1 > p.N - 4) f1 = p.N - 4;
-            v0 += *(const f32x4*)(rp + f0);
-            if (pair) v1 += *(const f32x4*)(rp + f1);
+            v0 += first_read(*(const f32x4*)(rp + f0));
+            if (pair) v1 += first_read(*(const f32x4*)(rp + f1));
           }
           if (!row_ok || f >= p.N) continue;
           if (dbg & 64) {
@@ -732,7 +672,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
         int64_t f = n0 + wn * WN + feat_of(j, fg);
         if (f > p.N - 4) f = p.N - 4;  // clamp loads; stores are guarded below
         fj[j] = (int)f;
-        bj[j] = p.bias ? *(const f32x4*)(p.bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bj[j] = p.bias ? first_read(*(const f32x4*)(p.bias + f)) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       // GroupNorm statistics of the tensor being written (ch_stats): the wave's 64 rows x WN channels are summed here, while
       // the values are in registers, so that the consuming GroupNorm needs no statistics pass over the fp32 tensor.
@@ -760,7 +700,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
         if (p.row_add && !(dbg & 32)) {
           const float* rp = p.row_add + (mc / p.rows_per_group) * p.ldra;
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) v[j] += *(const f32x4*)(rp + fj[j]);
+          for (int j = 0; j < NJ; ++j) v[j] += first_read(*(const f32x4*)(rp + fj[j]));
         }
         const bool row_ok = m < p.M;
         if constexpr (STATS_OK) {
@@ -864,7 +804,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false, bool FP8 = false, bool SPLITK = false, int NW = 4, bool LNP = false>
+template <int BM, int BN, int MODE, int EPI, bool PAIRED, bool ASTAT = false, bool FP8 = false, bool SPLITK = false, int NW = 4>
 int launch_p(const GemmArgs& a, hipStream_t s) {
   // + bias slots (ASYNC) + weight-scale slots (FP8 ASYNC)
   constexpr int lds = 2 * ((ASTAT ? 0 : BM) + BN) * 128 + (ASTAT ? 8192 : PAIRED ? 4096 : 0) + (FP8 && PAIRED ? 4096 : 0);
@@ -876,7 +816,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK, NW, LNP>,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK, NW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (DBG_BUILD)
       (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, EPI, true, PAIRED, false>,
@@ -929,7 +869,7 @@ int launch_p(const GemmArgs& a, hipStream_t s) {
       return seva_check_launch("gemm_kernel");
     }
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK, NW, LNP>), dim3((unsigned)nb), dim3(64 * NW), lds, s, args);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, EPI, false, PAIRED, ASTAT, FP8, SPLITK, NW>), dim3((unsigned)nb), dim3(64 * NW), lds, s, args);
   return seva_check_launch("gemm_kernel");
 }
 
@@ -949,14 +889,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     if constexpr (MODE == 0 && BN >= 128) {
       if (a.out_f16 && !a.out_f32 && !a.residual) {
         if constexpr (BM == 128 && !FP8) {
-          if (astat_on && !dbg_run && a.K <= 320) {
-            if (a.ln_x) return launch_p<BM, BN, MODE, EPI, true, true, FP8, false, 4, true>(a, s);
-            return launch_p<BM, BN, MODE, EPI, true, true, FP8>(a, s);
-          }
-        }
-        if (a.ln_x) {
-          seva_set_error("gemm: LayerNorm prologue requested on a launch that cannot take the A-in-registers kernel");
-          return SEVA_ERR_ARG;
+          if (astat_on && !dbg_run && a.K <= 320) return launch_p<BM, BN, MODE, EPI, true, true, FP8>(a, s);
         }
         return launch_p<BM, BN, MODE, EPI, true, false, FP8>(a, s);
       }
@@ -971,16 +904,7 @@ namespace {
 template <bool FP8>
 int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   SEVA_REQUIRE(d != nullptr, "gemm: null desc");
-  SEVA_REQUIRE((d->a || d->ln_x) && d->w, "gemm: null operand");
-  if (d->ln_x) {
-    SEVA_REQUIRE(!FP8 && d->mode == 0 && d->epilogue == 0 && d->K <= 320 && d->out_f16 && !d->out_f32 && !d->residual && d->N >= 128 &&
-                     g_seva_knobs.gemm_astat != 0 && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0,
-                 "gemm: the LayerNorm prologue runs on the A-in-registers kernel only (plain mode and epilogue, K <= 320, f16-only "
-                 "output, N >= 128, knobs gemm_astat / gemm_dbg / gemm_stagger at their defaults)");
-    SEVA_REQUIRE(d->ln_gamma && d->ln_beta && d->ldx >= d->K && d->ldx % 4 == 0 &&
-                     ((uintptr_t)d->ln_x | (uintptr_t)d->ln_gamma | (uintptr_t)d->ln_beta) % 16 == 0,
-                 "gemm: LayerNorm prologue needs gamma, beta, a row pitch >= K (multiple of 4) and 16-byte aligned pointers");
-  }
+  SEVA_REQUIRE(d->a && d->w, "gemm: null operand");
   SEVA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%lld N=%lld K=%lld",
                (long long)d->M, (long long)d->N, (long long)d->K);
   constexpr int KU = FP8 ? 2 : 1;  // e4m3 elements per 2-byte unit of the kernel's K / lda / cin arithmetic
@@ -1016,7 +940,6 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   a.out_f8 = (uint8_t*)d->out_f8;
   a.w_exp = (const uint8_t*)d->w_exp;
   a.ch_stats = d->ch_stats;
-  a.ln_x = d->ln_x; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ldx = d->ldx; a.ln_eps = d->ln_eps;
   a.sk_ws = nullptr;
   SEVA_REQUIRE(!d->ch_stats || (d->out_f32 && d->epilogue == 0 && d->N >= 128 && (uintptr_t)d->ch_stats % 16 == 0 &&
                                 d->col_scale_n == 0),
@@ -1056,12 +979,12 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     a.stride = d->stride; a.upsample = d->upsample;
     a.pad_lo = d->pad_br_only ? 0 : 1;
   } else {
-    SEVA_REQUIRE(d->ln_x || (d->lda >= d->K && d->lda % (8 * KU) == 0), "gemm: lda=%lld invalid", (long long)d->lda);
+    SEVA_REQUIRE(d->lda >= d->K && d->lda % (8 * KU) == 0, "gemm: lda=%lld invalid", (long long)d->lda);
   }
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
   // algorithmic HBM bytes: A (conv: the NHWC image) and W read once, residual read once, each output written once
-  const double a_elems = (d->mode == 1 ? (double)d->n * d->ih * d->iw * d->cin : (double)d->M * (double)d->K) * (d->ln_x ? 2.0 : 1.0);
+  const double a_elems = (d->mode == 1 ? (double)d->n * d->ih * d->iw * d->cin : (double)d->M * (double)d->K);
   const double a2_bytes = (d->mode == 1 && d->a2) ? 2.0 * (double)d->M * (double)d->K2 : 0.0;
   const double n_out = d->epilogue == 1 ? (double)d->N / 2 : (double)d->N;
   const double esz = FP8 ? 1.0 : 2.0;
@@ -1105,7 +1028,6 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   bool half_m = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
   if (g_seva_knobs.gemm_bm > 0) half_m = g_seva_knobs.gemm_bm == 64;
   if (d->ch_stats) half_m = false;  // statistics are emitted per wave-owned 64-row block: 128-row tiles only
-  if (d->ln_x) half_m = false;      // the LayerNorm prologue lives in the 128-row A-in-registers kernel
   const bool two_src = d->mode == 1 && d->a2 != nullptr;  // MODE 3: instantiated for 128- and 160-row tiles, never split-K
   if (two_src) half_m = false;
   // Split-K = 2 for convolutions over SMALL IMAGES (<= 128 output pixels per sample: the ds8 level, 9 x 9) with a long
@@ -1116,13 +1038,14 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     const int bn = (g_seva_knobs.gemm_bn > 0 ? g_seva_knobs.gemm_bn == 160 : d->N % 160 == 0) ? 160 : 128;
     const int64_t tiles = ((d->M + 127) / 128) * ((d->N + bn - 1) / bn);
     SEVA_REQUIRE((uintptr_t)d->splitk_ws % 16 == 0, "gemm: splitk_ws must be 16-byte aligned");
-    // a workspace that cannot hold this launch's tiles (a larger batch than it was sized for) is not an error: the launch
-    // simply is not split and takes the 64-row-tile kernel it used before split-K existed.  The split decision inside the
-    // capacity range still looks at per-sample dimensions only.
-    if (tiles < 16383 && d->splitk_ws_bytes >= (int64_t)(16384 + tiles * 128 * bn) * 4) {
-      a.sk_ws = d->splitk_ws;
-      half_m = false;
-    }
+    // A workspace that cannot hold this launch's tiles is an ERROR (it was a silent fall-back to the unsplit 64-row kernel in
+    // round 3: the reduction order of a sample would then have depended on the batch it was launched in and on the size of the
+    // caller's workspace -- the opposite of what the per-sample split rule promises).  Size it with the formula of seva_hip.h.
+    SEVA_REQUIRE(tiles < 16383 && d->splitk_ws_bytes >= (int64_t)(16384 + tiles * 128 * bn) * 4,
+                 "gemm: splitk_ws too small for this launch: %lld tiles of 128 x %d need %lld bytes (and fewer than 16383 tiles), got %lld",
+                 (long long)tiles, bn, (long long)((16384 + tiles * 128 * bn) * 4), (long long)d->splitk_ws_bytes);
+    a.sk_ws = d->splitk_ws;
+    half_m = false;
   }
   // 3x3 / stride 1 / pad 1 convs whose tile window fits LDS: the input window (+ halo) is staged once per 64-channel slab and the nine
   // taps read it through shifted fragment addresses (conv_win.hip); everything else keeps the per-tap gather below

@@ -19,11 +19,6 @@ struct SevaGemmArgs {
   const half_t* a2;       // MODE 3: second A operand [M][lda2] whose K2 columns follow the conv's 9 * cin (K = 9 cin + K2)
   int64_t lda2;
   int32_t nk1;            // MODE 3: K-tiles of the conv part (9 * cin / 64)
-  const float* ln_x;      // ASTAT kernel only: A = LayerNorm(ln_x[M][ldx]) * ln_gamma + ln_beta over K columns (a is ignored)
-  const float* ln_gamma;
-  const float* ln_beta;
-  int64_t ldx;
-  float ln_eps;
   int64_t M, N, K;        // FP8 kernels: K, lda, cin count 2-byte units (= pairs of e4m3 elements)
   int64_t lda, ldr, ldo32, ldo16, ldo8;
   int64_t rows_per_group, ldra;

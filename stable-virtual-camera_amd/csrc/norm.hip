@@ -79,7 +79,7 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(GnArgs p) {
     for (int q = mp.q0; q < mp.cq; q += mp.qstep) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
       for (int pix = p_begin + mp.pl; pix < p_end; pix += mp.pl_count) {
-        const f32x4 v = load_quad(p, n, pix, q * 4);
+        const f32x4 v = first_read(load_quad(p, n, pix, q * 4));  // (summed with packed adds: the first-reader rule, seva_common.h)
         s += v;
         ss += v * v;
       }
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(GnArgs p) {
     float s = 0.f, ss = 0.f;
     for (int pl = 0; pl < mp.pl_count; ++pl)
       for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        s += lsum[pl * C + c];
-        ss += lsq[pl * C + c];
+        s += first_read(lsum[pl * C + c]);
+        ss += first_read(lsq[pl * C + c]);
       }
     float* o = p.ws + (((int64_t)n * nslab + slab) * p.groups + g) * 2;
     o[0] = s;
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = c0 + r, g = c / cpg;
-      a[r] = g_rstd[g] * p.gamma[c];
-      b[r] = p.beta[c] - g_mean[g] * a[r];
-      bmod[r] = f32x2{1.0f + (dc ? p.dense_b[c] : 0.f), dc ? p.dense_b[C + c] : 0.f};
+      a[r] = first_read(g_rstd[g]) * first_read(p.gamma[c]);
+      b[r] = first_read(p.beta[c]) - first_read(g_mean[g]) * a[r];
+      bmod[r] = f32x2{1.0f + (dc ? first_read(p.dense_b[c]) : 0.f), dc ? first_read(p.dense_b[C + c]) : 0.f};
 #pragma unroll
       for (int j = 0; j < ND; ++j) wmod[r][j] = f32x2{0.f, 0.f};
     }
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
       f32x4 ws4[6], wh4[6];
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
-        ws4[t] = *(const f32x4*)(p.dense_w + (int64_t)c0 * 6 + 4 * t);
-        wh4[t] = *(const f32x4*)(p.dense_w + (int64_t)(C + c0) * 6 + 4 * t);
+        ws4[t] = first_read(*(const f32x4*)(p.dense_w + (int64_t)c0 * 6 + 4 * t));
+        wh4[t] = first_read(*(const f32x4*)(p.dense_w + (int64_t)(C + c0) * 6 + 4 * t));
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int i = sub + 16 * k < cq ? sub + 16 * k : cq - 1;
-      gm[HOIST ? k : 0] = *(const f32x4*)(gamma + i * 4);
-      bt[HOIST ? k : 0] = *(const f32x4*)(beta + i * 4);
+      gm[HOIST ? k : 0] = first_read(*(const f32x4*)(gamma + i * 4));
+      bt[HOIST ? k : 0] = first_read(*(const f32x4*)(beta + i * 4));
     }
   }
   auto load_row = [&](int64_t row, f32x4 (&v)[NV]) {
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       for (int k = 0; k < NV; ++k) {
         const int i = sub + 16 * k;
         if (i < cq) {
-          const f32x4 g4 = HOIST ? gm[HOIST ? k : 0] : *(const f32x4*)(gamma + i * 4);
-          const f32x4 b4 = HOIST ? bt[HOIST ? k : 0] : *(const f32x4*)(beta + i * 4);
+          const f32x4 g4 = HOIST ? gm[HOIST ? k : 0] : first_read(*(const f32x4*)(gamma + i * 4));
+          const f32x4 b4 = HOIST ? bt[HOIST ? k : 0] : first_read(*(const f32x4*)(beta + i * 4));
           if constexpr (OUT != 0) {
             float y[4];
 #pragma unroll
@@ -429,20 +429,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   half_t* orow = out + (int64_t)blockIdx.x * ldo;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float mx = -1e30f;
-  for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, xr[c] * scale_log2);
+  for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, first_read(xr[c]) * scale_log2);
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float s = 0.f;
-  for (int c = threadIdx.x; c < cols; c += 256) s += __builtin_amdgcn_exp2f(xr[c] * scale_log2 - mx);
+  for (int c = threadIdx.x; c < cols; c += 256) s += __builtin_amdgcn_exp2f(first_read(xr[c]) * scale_log2 - mx);
   s = wave_sum(s);
   if (lane == 0) red[wave] = s;
   __syncthreads();
   const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
   for (int c = threadIdx.x; c < cols_pad; c += 256)
-    orow[c] = (half_t)(c < cols ? __builtin_amdgcn_exp2f(xr[c] * scale_log2 - mx) * inv : 0.f);
+    orow[c] = (half_t)(c < cols ? __builtin_amdgcn_exp2f(first_read(xr[c]) * scale_log2 - mx) * inv : 0.f);
 }
 
 int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

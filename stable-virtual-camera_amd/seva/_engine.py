@@ -117,11 +117,6 @@ class SevaEngine:
         self.conv_splitk = _os.environ.get("SEVA_CONV_SPLITK", "1") != "0"  # 0: 64-row tiles at the 9x9 level (A/B runs)
         self.attn_split = _os.environ.get("SEVA_ATTN_SPLIT_KV", "1") != "0"  # 0: joint attention never K/V-split (A/B runs)
         self.attn_split_max = max(2, min(4, int(_os.environ.get("SEVA_ATTN_SPLIT", "2"))))  # workspace slots (knob attn_split: 2..4)
-        # 1: LayerNorm in the prologue of the C = 320 QKV projection (seva_gemm_desc.ln_x).  OFF by default -- measured neutral to
-        # negative (tools/kqkv_ln.py, profiles/r03_kqkv_ln.log: LayerNorm + QKV 324.7 us vs fused 324.8 us at the 72x72 level; in the
-        # step the norm class drops 0.75 ms and the GEMM class rises 1.0 ms): inside the GEMM the 160 KB of fp32 rows per workgroup
-        # are latency-exposed loads in two 80-register batches, where the LayerNorm kernel streams at 5.3 TB/s.
-        self.qkv_ln_fused = _os.environ.get("SEVA_QKV_LN_FUSED", "0") == "1"
         # 1: the ResBlock's 1x1 skip conv as extra K-tiles of its second 3x3 conv (one accumulation, no fp32 round trip of the skip
         # result, a launch fewer).  OFF by default -- measured neutral (profiles/r03_ab_fold_skip.log: 96.9 vs 96.5 ms per step over two
         # interleaved rounds, GEMM class -2.0 ms, conv class +1.2 ms).  Not at levels whose convs run split-K (images <= 128 px).
@@ -477,10 +472,6 @@ class SevaEngine:
         if at_pfx + ".qkv8" in W:  # fp8 mode: e4m3 LayerNorm output x e4m3 weights, f16 q/k/v out
             a8 = self._ln(x32, ln_pfx, rows, c, fp8=True)
             ops.gemm(a8, W[at_pfx + ".qkv8"], w_exp=W[at_pfx + ".qkv8e"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)
-        elif self.qkv_ln_fused and c <= ops.GEMM_LN_MAX_K and c % 64 == 0 and 3 * c >= 128:
-            # narrow level (C = 320): LayerNorm runs in the projection's prologue (A panel normalised in registers)
-            ops.gemm(None, W[at_pfx + ".qkv"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c,
-                     ln_x=x32, ln_gamma=W[ln_pfx + ".g"], ln_beta=W[ln_pfx + ".b"], ln_eps=1e-5)
         else:
             a = self._ln(x32, ln_pfx, rows, c)
             ops.gemm(a, W[at_pfx + ".qkv"], out_f16=qkv, col_scale=QK_SCALE_LOG2E, col_scale_n=c)

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEVA_HIP_LIB: A/B benchmarking of two builds of the same library (tools/); default = the in-tree build
 LIB_PATH = os.environ.get("SEVA_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libseva_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 PROF_CLASSES = 5
 PROF_NAMES = ("gemm", "conv", "attention", "norm", "elementwise")
 
@@ -38,7 +38,6 @@ class GemmDesc(C.Structure):
         ("col_scale", c_float), ("col_scale_n", c_int32), ("pad_br_only", c_int32),
         ("w_exp", c_void_p), ("out_f8", c_void_p), ("ldo8", c_int64),
         ("ch_stats", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
-        ("ln_x", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ldx", c_int64), ("ln_eps", c_float),
         ("a2", c_void_p), ("lda2", c_int64), ("K2", c_int64),
     ]
 

@@ -41,14 +41,8 @@ def gemm(
     out_f8: torch.Tensor | None = None,
     ch_stats: torch.Tensor | None = None,
     splitk_ws: torch.Tensor | None = None,
-    ln_x: torch.Tensor | None = None,
-    ln_gamma: torch.Tensor | None = None,
-    ln_beta: torch.Tensor | None = None,
-    ln_eps: float = 1e-5,
 ) -> None:
     """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16).
-    ln_x ([M, K] f32, with ln_gamma / ln_beta; a = None): A = LayerNorm(ln_x) computed in the kernel's prologue
-    (seva_gemm_desc.ln_x: K <= 320, f16-only output).
     splitk_ws (`splitk_workspace`): lets fp32-output launches with a partly filled last round of workgroup slots run as stream-K.
     ch_stats (`channel_stats_buffer`): receives per-64-row-block, per-channel sum / sum of squares of out_f32 (GroupNorm
     statistics emitted by the epilogue; `groupnorm(stats1=...)`).
@@ -56,24 +50,16 @@ def gemm(
     fp8 mode (seva_gemm_fp8): a, w are uint8 tensors of e4m3 bytes and w_exp [N] uint8 the weights' E8M0 scale bytes;
     out_f8 (GEGLU epilogue only) receives the hidden activations as e4m3."""
     fp8 = w_exp is not None
-    if ln_x is not None:
-        require_cuda(ln_x, w)
-        assert a is None and not fp8 and ln_x.dtype == F32 and ln_x.dim() == 2 and ln_x.stride(1) == 1 and w.dtype == F16
-        assert ln_gamma is not None and ln_beta is not None and ln_gamma.dtype == F32 and ln_beta.dtype == F32
-        M, K = ln_x.shape
-    else:
-        require_cuda(a, w)
-        assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype == (U8 if fp8 else F16)
-        M, K = a.shape
+    require_cuda(a, w)
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype == (U8 if fp8 else F16)
+    M, K = a.shape
     N = w.shape[0]
     d = GemmDesc()
     d.a, d.w = ptr(a), w.data_ptr()
-    if ln_x is not None:
-        d.ln_x, d.ln_gamma, d.ln_beta, d.ldx, d.ln_eps = ln_x.data_ptr(), ln_gamma.data_ptr(), ln_beta.data_ptr(), ln_x.stride(0), ln_eps
     d.bias, d.row_add, d.residual = ptr(bias), ptr(row_add), ptr(residual)
     d.out_f32, d.out_f16 = ptr(out_f32), ptr(out_f16)
     d.M, d.N, d.K = M, N, K
-    d.lda = a.stride(0) if a is not None else 0
+    d.lda = a.stride(0)
     d.ldr = residual.stride(0) if residual is not None else 0
     d.ldo32 = out_f32.stride(0) if out_f32 is not None else 0
     d.ldo16 = out_f16.stride(0) if out_f16 is not None else 0
@@ -94,8 +80,6 @@ def gemm(
         assert out_f8 is None
         check(_lib().seva_gemm_f16(C.byref(d), stream_ptr(w.device)), "seva_gemm_f16")
 
-
-GEMM_LN_MAX_K = 320  # widest reduction of `gemm(ln_x=...)` (the A-in-registers kernel holds K <= 320)
 
 
 STATS_ROWS = 64  # rows per block of the epilogue-emitted GroupNorm statistics (include/seva_hip.h: seva_gemm_desc.ch_stats)

@@ -84,10 +84,7 @@ def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, ou
 
 def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, residual=None,
          out_f32=None, out_f16=None, geglu=False, col_scale=1.0, col_scale_n=0, w_exp=None, out_f8=None, ch_stats=None,
-         splitk_ws=None, ln_x=None, ln_gamma=None, ln_beta=None, ln_eps=1e-5):
-    if ln_x is not None:  # LayerNorm prologue (seva_gemm_desc.ln_x)
-        assert a is None and out_f32 is None and residual is None and not geglu and ln_x.shape[1] <= 320
-        a = F.layer_norm(ln_x, (ln_x.shape[1],), ln_gamma, ln_beta, ln_eps).half()
+         splitk_ws=None):
     M, N = a.shape[0], w.shape[0]
     if w_exp is not None:  # seva_gemm_fp8
         assert a.dtype == U8 and w.dtype == U8 and a.shape[1] % 128 == 0 and N % 16 == 0
@@ -155,7 +152,6 @@ def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per
 
 
 ATTN_SPLIT_MIN_LK = 6144
-GEMM_LN_MAX_K = 320
 
 
 def attention_split_workspace_numel(batch, heads, lq, nsplit=2):

@@ -123,31 +123,6 @@ def _need_exp_lib(what):
         pytest.skip(f"production libseva_hip.so does not carry {what} (experimental library only)")
 
 
-@pytest.mark.parametrize("M,C,N", [(300, 320, 960), (1000, 64, 192), (515, 256, 768), (130, 128, 384), (4097, 320, 320)])
-def test_gemm_layernorm_prologue(dev, M, C, N):
-    """seva_gemm_desc.ln_x: A = LayerNorm(x) normalised in the A-in-registers kernel's prologue, against (a) the LayerNorm
-    kernel followed by the same GEMM (same math, f16 roundings of the normalised row flip at ties only) and (b) fp32 torch."""
-    from seva import ops
-    g = torch.Generator().manual_seed(77)
-    x = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dev)
-    gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
-    w = (torch.randn(N, C, generator=g) * C ** -0.5).half().to(dev)
-    bias = (0.2 * torch.randn(N, generator=g)).to(dev)
-    a16 = torch.empty((M, C), device=dev, dtype=torch.float16)
-    ops.layernorm(x, gm, bt, a16)
-    want = torch.empty((M, N), device=dev, dtype=torch.float16)
-    ops.gemm(a16, w, bias=bias, out_f16=want, col_scale=0.18, col_scale_n=C if N >= 2 * C else 0)
-    got = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
-    ops.gemm(None, w, bias=bias, out_f16=got, col_scale=0.18, col_scale_n=C if N >= 2 * C else 0, ln_x=x, ln_gamma=gm, ln_beta=bt)
-    ref = F.layer_norm(x, (C,), gm, bt, 1e-5) @ w.float().T + bias
-    if N >= 2 * C:
-        ref[:, :C] *= 0.18
-    assert torch.isfinite(got).all()
-    assert rel_l2(got, want) < 3e-4 and rel_l2(got, ref) < 1e-3
-    with pytest.raises(Exception):  # fp32 outputs / residuals stay on the staged-A kernels: asking for the prologue there is an error
-        ops.gemm(None, w, out_f32=torch.empty((M, N), device=dev), ln_x=x, ln_gamma=gm, ln_beta=bt)
-
-
 @pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 4, 64), (777, 960, 640), (4097, 132, 192)])
 def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg, knobs):
@@ -247,13 +222,56 @@ def test_tile_160x160_bitwise_equal(dev, kind, shape, knobs):
     radd = _rand(((M + rpg - 1) // rpg, N), dev, 5)
     outs = []
     for bm in (160, 128, 64, -1):
-        knobs(gemm_bm=bm)
+        knobs(gemm_bm=bm, conv_win=0)  # the per-tap kernel's tile shapes (the window kernel reduces slab-outer: its own tests below)
         o = torch.full((M, N), float("nan"), device=dev)
         fn(o)
         outs.append(o)
     assert torch.isfinite(outs[0]).all()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+WIN_CASES = [  # n, ih, iw, cin, cout, statistics
+    (42, 18, 18, 128, 320, False), (5, 36, 36, 64, 640, False), (2, 72, 72, 64, 320, True), (3, 9, 9, 128, 160, False),
+    (5, 7, 11, 64, 320, False), (1, 33, 31, 192, 160, False), (2, 16, 16, 64, 160, True), (7, 5, 4, 128, 320, False),
+    (4, 24, 40, 128, 480, False), (3, 8, 8, 64, 160, True),
+]
+
+
+@pytest.mark.parametrize("n,ih,iw,cin,cout,stats", WIN_CASES)
+def test_conv3x3_window_kernel(dev, n, ih, iw, cin, cout, stats, knobs):
+    """csrc/conv_win.hip (reference convs: seva/modules/layers.py:101,113): the tile's input window + halo staged in LDS once per
+    64-channel slab, nine taps from shifted fragment addresses.  Integer data: bit-exact against torch for both instantiation
+    families (two 4-wave workgroups per CU / one 8-wave 256-row tile), with bias + row_add + residual and epilogue-emitted
+    GroupNorm statistics; tiles that straddle images (18 x 18, 9 x 9, 5 x 4), per-image tiling (72 x 72), M tails, windows
+    cut by the end of the batch.  Random data: the two families agree bit for bit (same reduction order) and differ from the
+    per-tap kernel only by the order of the fp32 additions (slab-outer instead of tap-outer)."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    M, hw = n * ih * iw, ih * iw
+    x = _ints((n, cin, ih, iw), -3, 3, dev, 1)
+    w = _ints((cout, cin, 3, 3), -2, 2, dev, 2)
+    bias, emb, res = _ints((cout,), -4, 4, dev, 3), _ints((n, cout), -2, 2, dev, 4), _ints((n, hw, cout), -5, 5, dev, 5)
+    ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1).reshape(n, hw, cout) + emb[:, None, :] + res
+    xh, wp = x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w)
+    for fam in (1, 2):
+        knobs(conv_win=fam)
+        out = torch.full((n, hw, cout), float("nan"), device=dev)
+        st = torch.full(ops.channel_stats_shape(M, cout), float("nan"), device=dev) if stats else None
+        ops.conv3x3(xh, wp, bias=bias, row_add=emb, rows_per_group=hw, residual=res, out_f32=out, ch_stats=st)
+        assert torch.equal(out, ref), f"family {fam}: max diff {(out - ref).abs().max()}"
+        if st is not None:
+            assert torch.equal(st.double(), _block_stats(out.view(M, cout), M, cout))
+    xr, wr = _rand((n, ih, iw, cin), dev, 6).half(), pack_conv3x3(_rand((cout, cin, 3, 3), dev, 7, 0.05).cpu()).half().to(dev)
+    rr = _rand((n, hw, cout), dev, 8)
+    outs = []
+    for fam in (0, 1, 2):
+        knobs(conv_win=fam)
+        o = torch.full((n, hw, cout), float("nan"), device=dev)
+        ops.conv3x3(xr, wr, bias=bias, residual=rr, out_f32=o)
+        outs.append(o)
+    assert torch.equal(outs[1], outs[2])
+    assert rel_l2(outs[1], outs[0]) < 3e-6
 
 
 CONV_CASES = [  # n, ih, iw, cin, cout, stride, upsample
@@ -748,6 +766,23 @@ def test_conv3x3_with_folded_second_operand(dev, n, ih, iw, cin, cout, k2, stats
     assert torch.equal(o, ref), f"max diff {(o - ref).abs().max()}"
     if st is not None:
         assert torch.equal(st.double(), _block_stats(o, M, cout))
+
+
+def test_conv_splitk_workspace_too_small_is_an_error(dev):
+    """A split-K workspace sized for a smaller batch is refused (it used to fall back silently to the unsplit kernel, which
+    made a sample's reduction order depend on the batch it was launched in and on the caller's workspace)."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    from seva._native import SevaNativeError
+    n, cin, cout = 42, 1280, 1280
+    x = _ints((n, 9, 9, cin), -2, 2, dev, 1).half()
+    w = pack_conv3x3(_ints((cout, cin, 3, 3), -1, 1, dev, 2)).half().to(dev)
+    out = torch.empty((n * 81, cout), device=dev)
+    small = ops.splitk_workspace(2 * 81, cout, dev)[: 16384 + 4 * 128 * 160].contiguous()  # 4 tile slots; the launch has 27 x 8 tiles
+    with pytest.raises(SevaNativeError, match="splitk_ws too small"):
+        ops.conv3x3(x, w, out_f32=out, splitk_ws=small)
+    ops.conv3x3(x, w, out_f32=out, splitk_ws=ops.splitk_workspace(n * 81, cout, dev))  # the right size runs
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("n,ih,iw,cin,cout,stride", [(42, 9, 9, 1280, 1280, 1), (5, 9, 9, 256, 320, 1), (42, 18, 18, 640, 1280, 2),

@@ -109,7 +109,12 @@ def _worker(rank, world, port, q, first_pass, extra=None):
     _patch_cpu()
     timers = {}
     res = _run(first_pass_strategy=first_pass, timers=timers, **(extra or {}))
-    q.put((rank, res["latents"].numpy() if "latents" in res else None, sorted(timers)))
+    pairs = None
+    if (extra or {}).get("cfg_split"):
+        from seva import pipeline
+        # the pair groups every rank holds, in creation order (new_group is collective: all ranks must create them identically)
+        pairs = [tuple(dist.get_process_group_ranks(g)) for g in pipeline.cfg_pair_groups()]
+    q.put((rank, res["latents"].numpy() if "latents" in res else None, sorted(timers), pairs))
     dist.destroy_process_group()
 
 
@@ -195,12 +200,14 @@ def test_second_pass_schedule_with_cfg_split():
     assert sum(0.5 if len(r[0][1]) == 2 else 1.0 for r in second_pass_schedule(10, 8, True)) == 1.5
 
 
-@pytest.mark.parametrize("world,n", [(2, 100), (4, 168)])
+@pytest.mark.parametrize("world,n", [(2, 100), (4, 168), (8, 168)])
 def test_cfg_split_trajectory_equals_single_process(world, n, monkeypatch):
     """CFG-split: the first-pass window on the pair (0,1) and the leftover second-pass round on pairs,
     each rank of a pair running one half of every CFG batch with one all-gather per step -- the trajectory is bit for bit
     the single-process one (gloo; world 2: an odd number of second-pass windows so that the last one is split;
-    world 4: the 168-view plan, 10 windows = 4 + 4 + a pair round of 2)."""
+    world 4: the 168-view plan, 10 windows = 4 + 4 + a pair round of 2; world 8 = the target machine's rank count: the
+    168-view plan as one round of 8 whole windows + a pair round of 2 on (0,1), (2,3)).  Every rank creates the same pair
+    groups in the same order."""
     from conftest import PKG
     from seva import pipeline
     here = os.path.dirname(os.path.abspath(__file__))
@@ -224,3 +231,7 @@ def test_cfg_split_trajectory_equals_single_process(world, n, monkeypatch):
     got = torch.from_numpy(res[0][1])
     assert all(r[1] is None for r in res[1:])
     assert torch.equal(got, ref), float((got - ref).abs().max())
+    # every rank holds world / 2 pair groups, created in the same order; entry rank // 2 is the rank's own pair (the entries of
+    # pairs a rank does not belong to are non-member handles)
+    for rank, _, _, pairs in res:
+        assert len(pairs) == world // 2 and pairs[rank // 2] == (2 * (rank // 2), 2 * (rank // 2) + 1), (rank, pairs)

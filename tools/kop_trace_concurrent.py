@@ -2,7 +2,8 @@
 """Which operator's OUTPUT changes between identical forwards of the tiny UNet while a second stream of the same process keeps the
 card busy?  Every seva.ops call of the main thread is followed by a device sync and a byte-sum of all its tensor arguments; the first
 call whose sums differ from the first pass, with equal sums for everything before it, is the operator that was not repeatable."""
-import inspect, os, sys, threading, time
+import faulthandler, gc, inspect, os, sys, threading, time
+faulthandler.enable()  # a SIGABRT / SIGSEGV of this process leaves the Python stacks of all threads on stderr
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import torch
@@ -25,15 +26,23 @@ def inputs(seed):
 stop = False
 
 
-def load():
+def load(net2):
+    """The load generator: forwards of a SECOND engine on a second stream.  Everything it creates on the device dies HERE, before the
+    thread returns: round 3's TAG=full run ended in `terminate called without an active exception` at interpreter exit, after its results
+    were printed (profiles/r03_concurrency_op_trace_1p3b.log); the tiny run never did.  What the full run had and the tiny one had not: the
+    1.3 B synthetic state_dict was generated INSIDE this thread (CPU tensors large enough for torch's intra-op thread team, owned by a
+    thread that no longer exists at exit) and a 14 GB arena, its graph-capture pool and the side stream's events were left to the
+    interpreter's teardown.  Now the weights are built on the main thread and this thread frees what it made."""
     s2 = torch.cuda.Stream()
     with torch.cuda.stream(s2):
-        net, _ = _build(TAG, dev)
-        eng = net.engine(); eng.use_graph = False
+        eng = net2.engine(); eng.use_graph = False
         a = inputs(11)
         while not stop:
             for _ in range(10): eng.forward(*a, T)
             s2.synchronize()
+        s2.synchronize()
+        del eng, a
+    torch.cuda.synchronize()
 
 
 cur = []
@@ -70,7 +79,8 @@ eng = net.engine(); eng.use_graph = False
 a = inputs(5)
 th = None
 if os.environ.get("LOAD", "1") == "1":
-    th = threading.Thread(target=load); th.start(); time.sleep(10)
+    net2, _ = _build(TAG, dev)  # on the MAIN thread (see load())
+    th = threading.Thread(target=load, args=(net2,)); th.start(); time.sleep(10)
 first = {}
 for p in range(int(os.environ.get("PASSES", "60"))):
     cur.clear()
@@ -89,3 +99,10 @@ if th: th.join()
 print("first non-repeatable call per pass (operator, differing argument, shape): count", flush=True)
 for k, v in sorted(first.items(), key=lambda kv: -kv[1]): print("  ", k, v, flush=True)
 print("passes:", int(os.environ.get("PASSES", "60")), "calls per pass:", len(ref), flush=True)
+# explicit teardown in a defined order, on the main thread, while the HIP runtime is certainly alive
+del eng, net, a
+if th: del net2
+gc.collect()
+torch.cuda.synchronize()
+torch.cuda.empty_cache()
+print("teardown: engines, arenas and streams released; exiting normally", flush=True)
