@@ -93,8 +93,8 @@ typedef struct seva_gemm_desc {
    * sample, K >= 1024: the 9x9 level of a 576x576 step) as split-K = 2 on 128-row tiles: two workgroups per tile, the
    * upper half of K exported raw, added by the partner before the epilogue (fixed association: deterministic, and chosen
    * from per-sample dimensions only).  Layout: 16384 int flags (zero before first use; every launch leaves them zero), then
-   * one 128 x BN fp32 tile per output tile: splitk_ws_bytes >= 4 * (16384 + max(tiles, 512) * 128 * 160) (512 slots serve the
-   * opt-in stream-K kernel, knob gemm_streamk = 1, which fp32-output GEMMs and convs of >= 512 tiles then use).  The hand-off
+   * one 128 x BN fp32 tile per output tile: splitk_ws_bytes >= 4 * (16384 + tiles * 128 * 160), tiles = ceil(M / 128) *
+   * ceil(N / 160).  The hand-off
    * uses agent-scope (sc1) stores / loads, no cache-wide fence.  One launch at a time may
    * use a given workspace (launches on ONE stream are fine).  A workspace too small for a launch that qualifies for the split is
    * an ERROR (ABI 8; it was a silent fall-back to the unsplit kernel): whether a sample is split never depends on the batch. */
@@ -352,8 +352,9 @@ int seva_attention_small_f16(const void* q, const void* k, const void* v, void* 
 /* ------------------------------------------------------------------------------------------
  * Benchmark / debugging knobs.  The library reads its SEVA_* environment variables ONCE, when it is loaded (nothing
  * on the launch path calls getenv); a host changes a knob at run time with seva_set_knob (tests, tools).  Names:
- * gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat, attn_dbg, attn_no_tr, attn_two,
- * gn_min_iter, ff_variant (environment: SEVA_ + upper case).  -1 = unset (default heuristics).  None is needed in production.
+ * gemm_chunks, gemm_dbg, gemm_stagger, gemm_bm, gemm_bn, gemm_astat, attn_dbg, attn_no_tr, attn_two, attn_split,
+ * gn_min_iter, conv_win (0: per-tap conv gather everywhere; 1 / 2: force the 4-wave / 8-wave family of the window-staged conv kernel)
+ * (environment: SEVA_ + upper case).  -1 = unset (default heuristics).  None is needed in production.
  */
 int seva_set_knob(const char* name, int32_t value);
 int seva_get_knob(const char* name, int32_t* value);

@@ -781,347 +781,6 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs p, int64_t r
   *(half8_t*)(p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64 + q * p.o_sl + 8 * ch) = h;
 }
 
-#ifdef SEVA_EXPERIMENTAL  // experimental library only (make exp; knob attn_two = 3): measured +1 %, not shipped in libseva_hip.so
-// ---------------------------------------------------------------------------------------------
-// Software-pipelined kernel (engine path: pre-scaled q, tr-reads, lq > 32).  Same operand layouts, LDS tile images,
-// online-softmax arithmetic and rounding as attn_kernel<4, 64, true, false, true>; what changes is WHEN things issue.
-//
-// Measured (tools/micro/valu_rate.hip): one v_mfma_f32_32x32x16_f16 occupies the matrix pipe for 32.6 cycles but the issue
-// port for ~8; v_exp_f32 costs 8.2 cycles, v_max3 / v_cvt_pkrtz / v_dot2c 4.3, and a stream {1 MFMA, 3 v_exp} runs at 35
-// cycles per group with ONE wave per SIMD: VALU work issues in the shadow of the SAME wave's MFMA.  attn_kernel's tile is a
-// serial chain -- 8 score MFMAs -> max -> 32 exp -> pack -> 8 PV MFMAs -> row sums, ~1030 cycles per tile and wave against
-// 520 cycles of MFMA and ~540 of VALU work -- and three waves per SIMD behind a workgroup barrier per tile do not overlap it.
-// Here one iteration holds tile t's softmax VALU stream AND the MFMAs of two different tiles, 16 slots of
-//     { 1 MFMA ; ~1/16 of the VALU stream } :
-//   slots 0-7   score MFMAs of tile t+1 (into the other score block)  ||  exp2 / pack / row-sum of tile t, groups 0-2
-//   slots 8-15  PV MFMAs of tile t (group order)                      ||  group 3 of tile t, then the max chain of tile t+1
-// fenced with sched_barrier(0) so that program order IS the schedule.  The two score blocks swap roles every tile; the loop
-// body therefore handles two tiles (static register names, no rotation moves).  K/V ring of FOUR tiles (tile t+3 is issued
-// while V(t) and K(t+1) are read), 64 KiB of LDS, two workgroups per CU, <= 256 registers.
-#ifndef SEVA_ATTN3_ABL
-#define SEVA_ATTN3_ABL 0  // timing-only ablation build (tools/kattn3_ablate.sh): 1 no K/V reloads, 2 no exp / pack / row sums,
-#endif                    // 4 no PV MFMAs, 8 no score MFMAs, 16 no barrier, 32 fragments read once per iteration; results wrong
-template <int KT, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs p) {
-  constexpr int ABL = SEVA_ATTN3_ABL;
-  constexpr int KB = KT / 32, NBUF = 4;
-  static_assert(KT % (8 * NW) == 0 && NW * 32 * 128 <= NBUF * 2 * KT * 128, "tile rows split over the waves; O staging fits the ring");
-  static_assert(KT == 64, "the slot schedule below is written for 64-key tiles");
-  __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KT * 128];
-  constexpr int BUF_BYTES = 2 * KT * 128;
-  constexpr int IP = KT / 8 / NW;
-  constexpr int G = 2 * IP;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int qi = lane & 31, hh = lane >> 5;
-
-  int bid;
-  {
-    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
-    bid = ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
-  }
-  const int qb = bid % p.qblocks;
-  bid /= p.qblocks;
-  const int head = bid % p.heads;
-  const int batch = bid / p.heads;
-  const int b0 = batch / p.nb1, b1 = batch - b0 * p.nb1;
-
-  const half_t* const qbase = p.q + b0 * p.q_sb0 + b1 * p.q_sb1 + head * 64;
-  const half_t* const kbase = p.k + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
-  const half_t* const vbase = p.v + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64;
-  half_t* const obase = p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64;
-
-  const int qrow = qb * (32 * NW) + wave * 32 + qi;
-  const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
-  half8_t qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *(const half8_t*)(qbase + (int64_t)qrow_c * p.q_sl + 16 * s + 8 * hh);
-
-  f32x16 acc_o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
-  constexpr float RESCALE_THR = 8.0f;
-  float m_run = 0.f, l_run = 0.f;
-  f32x16 neg_m[2];  // -m_run as the C operand of the first score MFMA of each key block (two blocks: see attn_kernel)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) neg_m[0][r] = neg_m[1][r] = 0.f;
-
-  const int nt = (p.lk + KT - 1) / KT;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned smem_base =
-      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-  const int sr = lane >> 3, sp = lane & 7;
-  const half_t* kp[IP];
-  const half_t* vp[IP];
-#pragma unroll
-  for (int i = 0; i < IP; ++i) {
-    const int row = 8 * (wave_u * IP + i) + sr;
-    const int key = row < p.lk ? row : p.lk - 1;
-    kp[i] = kbase + (int64_t)key * p.k_sl + k_chunk_swz(row, sp) * 8;
-    vp[i] = vbase + (int64_t)key * p.k_sl + v_chunk_swz(row, sp) * 8;
-  }
-  const int64_t tile_stride = (int64_t)KT * p.k_sl;
-  const bool ragged = (p.lk % KT) != 0;
-  auto issue_tile = [&](int kt, int buf) {  // tiles are issued strictly in order 0, 1, 2, ...
-    const bool clamp = ragged && kt == nt - 1 && kt > 0;
-#pragma unroll
-    for (int i = 0; i < IP; ++i) {
-      const unsigned dst = smem_base + buf * BUF_BYTES + 8 * (wave_u * IP + i) * 128;
-      if (clamp) {
-        const int row = 8 * (wave_u * IP + i) + sr;
-        int key = kt * KT + row;
-        if (key >= p.lk) key = p.lk - 1;
-        const int64_t roff = (int64_t)key * p.k_sl;
-        glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
-        glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
-      } else {
-        glds16_raw(kp[i], dst);
-        glds16_raw(vp[i], dst + KT * 128);
-      }
-      kp[i] += tile_stride;
-      vp[i] += tile_stride;
-    }
-  };
-  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
-
-  typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
-  const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
-
-  // K fragment (s = k-step 0..3) of key block kb out of the K tile at lds_k
-  auto k_frag = [&](const char* lds_k, int kb, int s) {
-    const int krow = 32 * kb + qi;
-    return *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
-  };
-  // V^T fragment for output-dim block db and P group g = 2 * kb + s2 out of the V tile at lds_v
-  auto v_frag = [&](const char* lds_v, int db, int g) {
-    const int r0 = 16 * g + 4 * hh;  // 32 * kb + 16 * s2 + 4 * hh
-    const int colbyte = (32 * db + 16 * (g16 & 1) + 4 * p4) * 2;
-    const int ch = colbyte >> 4, within = colbyte & 15;
-    const int ra = r0 + q4, rb = r0 + 8 + q4;
-    return tr_read_pair(lds_v + ra * 128 + (v_chunk_swz(ra, ch) << 4) + within,
-                        lds_v + rb * 128 + (v_chunk_swz(rb, ch) << 4) + within);
-  };
-  // one softmax "pair unit": 2 exp2, 1 pack (round toward zero), 1 row-sum step (from the ROUNDED values) -- 25 issue cycles
-  float lsum4[4];
-  auto pair_unit = [&](const f32x16 (&sc)[KB], fp16x2_t (&pk)[4][4], int g, int j) {
-    const int kb = g >> 1, s2 = g & 1;
-    if (ABL & 2) {
-      pk[g][j] = __builtin_bit_cast(fp16x2_t, sc[kb][8 * s2 + 2 * j]);
-      asm volatile("" ::"v"(sc[kb][8 * s2 + 2 * j + 1]));
-      return;
-    }
-    const float e0 = __builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * j]);
-    const float e1 = __builtin_amdgcn_exp2f(sc[kb][8 * s2 + 2 * j + 1]);
-    pk[g][j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
-    lsum4[j] = __builtin_amdgcn_fdot2(pk[g][j], ones2, lsum4[j], false);
-  };
-  auto mask_tail = [&](f32x16 (&sc)[KB], int kt) {  // keys >= lk exist only in the last tile
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (key >= p.lk) sc[kb][r] = -1e30f;
-      }
-  };
-  // rescale on a new running maximum (wave-uniform, rare after the first tiles): `sc` are the scores of the tile whose maximum
-  // is `mx`, still relative to the old m_run
-  auto rescale = [&](f32x16 (&sc)[KB], float mx, bool first) {
-    if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {
-      const float delta = first ? mx : fmaxf(mx, 0.f);
-      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-      m_run += delta;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) neg_m[0][r] = neg_m[1][r] = -m_run;
-      asm volatile("" : "+v"(neg_m[0]), "+v"(neg_m[1]));
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
-    }
-  };
-#define SEVA_SLOT_END() __builtin_amdgcn_sched_barrier(0)
-
-  // ---- prologue: tiles 0..2 in flight, scores + maximum of tile 0 ----
-  issue_tile(0, 0);
-  if (nt > 1) issue_tile(1, 1);
-  if (nt > 2) issue_tile(2, 2);
-  if (nt > 2) wait_vm<2 * G>();
-  else if (nt > 1) wait_vm<G>();
-  else wait_vm<0>();
-#pragma unroll
-  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));  // retire the Q loads for hipcc's wait bookkeeping (see attn_kernel)
-  __syncthreads();
-  f32x16 scA[KB], scB[KB];
-  {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const half8_t kf = k_frag(smem, kb, s);
-        scA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], s == 0 ? neg_m[kb] : scA[kb], 0, 0, 0);
-      }
-    if (nt == 1 && ragged) mask_tail(scA, 0);
-    float mk[KB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      mk[kb] = scA[kb][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mk[kb] = fmaxf(mk[kb], scA[kb][r]);
-    }
-    rescale(scA, half_wave_max(fmaxf(mk[0], mk[1])), true);
-  }
-  // iteration 0 reads K of tile 1: it must have landed too (tile 2 may fly on)
-  if (nt > 2) wait_vm<G>();
-  else wait_vm<0>();
-  __syncthreads();
-
-  // ---- one pipelined iteration: softmax + PV of tile t (scores in `cur`), scores + maximum of tile t+1 (into `nxt`) ----
-  auto iter = [&](auto masked_next_c, int t, f32x16 (&cur)[KB], f32x16 (&nxt)[KB]) {
-    constexpr bool MASKED_NEXT = decltype(masked_next_c)::value;
-    const int bt = t & 3, bn = (t + 1) & 3;
-    const char* const lds_v = smem + bt * BUF_BYTES + KT * 128;  // V of tile t
-    const char* const lds_k = smem + bn * BUF_BYTES;             // K of tile t+1
-    const bool more3 = t + 3 < nt;
-    if (more3 && !(ABL & 1)) issue_tile(t + 3, (t + 3) & 3);  // that buffer held tile t-1: last read (V) in iteration t-1
-    fp16x2_t pk[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) lsum4[j] = 0.f;
-    half8_t kf[2];
-    kf[0] = k_frag(lds_k, 0, 0);
-    kf[1] = k_frag(lds_k, 1, 0);
-    SEVA_SLOT_END();
-    // slots 0-7: score MFMAs of tile t+1 (k-step major, the two key-block chains alternate); pair units 0..11 of tile t
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int s = i >> 1, kb = i & 1;
-      if (ABL & 8) {
-        if (s == 0) nxt[kb] = neg_m[kb];
-        asm volatile("" : "+v"(nxt[kb]) : "v"(kf[kb]), "v"(qf[s]));
-      } else {
-        nxt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb], qf[s], s == 0 ? neg_m[kb] : nxt[kb], 0, 0, 0);
-      }
-      if (i + 2 < 8 && !(ABL & 32)) kf[kb] = k_frag(lds_k, kb, s + 1);  // the fragment of slot i + 2
-      const int u0 = (3 * i) / 2, u1 = (3 * (i + 1)) / 2;  // 2, 1, 2, 1, ... pair units per slot
-#pragma unroll
-      for (int u = u0; u < u1; ++u) pair_unit(cur, pk, u >> 2, u & 3);
-      SEVA_SLOT_END();
-    }
-    // slots 8-15: PV MFMAs of tile t in group order; pair units 12..15 (group 3), then the max chain of tile t+1
-    half8_t vf[2];
-    vf[0] = v_frag(lds_v, 0, 0);
-    vf[1] = v_frag(lds_v, 1, 0);
-    float mk[KB];
-    SEVA_SLOT_END();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int g = i >> 1, db = i & 1;
-      const half8_t pf = __builtin_bit_cast(half8_t, pk[g]);
-      if (ABL & 4) asm volatile("" : "+v"(acc_o[db]) : "v"(vf[db]), "v"(pf));
-      else acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db], pf, acc_o[db], 0, 0, 0);
-      if (i + 2 < 8 && !(ABL & 32)) vf[db] = v_frag(lds_v, db, g + 1);
-      if (i < 4) {
-        pair_unit(cur, pk, 3, i);
-      } else {
-        if (i == 4) {  // (the score MFMAs of slots 0-7 are long retired: no result-hazard stall here)
-          if (MASKED_NEXT) mask_tail(nxt, t + 1);
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb) mk[kb] = nxt[kb][0];
-        }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)  // 2 x 15 running-max steps over slots 12..15 (as max3: 8 per slot)
-#pragma unroll
-          for (int r = 1 + 4 * (i - 4); r < 1 + 4 * (i - 3) && r < 16; ++r) mk[kb] = fmaxf(mk[kb], nxt[kb][r]);
-      }
-      SEVA_SLOT_END();
-    }
-    l_run += (lsum4[0] + lsum4[1]) + (lsum4[2] + lsum4[3]);
-    rescale(nxt, half_wave_max(fmaxf(mk[0], mk[1])), false);
-    // tile t+2 (issued in iteration t-1) must have landed before iteration t+1 reads its K; tile t+3's G instructions fly on
-    if (ABL & 1) {
-      wait_vm<0>();
-    } else {
-      if (more3) wait_vm<G>();
-      else wait_vm<0>();
-    }
-    if (!(ABL & 16)) __syncthreads();
-  };
-  // softmax + PV of the last tile (scores in `cur`)
-  auto last = [&](int t, f32x16 (&cur)[KB]) {
-    const char* const lds_v = smem + (t & 3) * BUF_BYTES + KT * 128;
-    fp16x2_t pk[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) lsum4[j] = 0.f;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) pair_unit(cur, pk, u >> 2, u & 3);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_frag(lds_v, db, g), __builtin_bit_cast(half8_t, pk[g]), acc_o[db], 0, 0, 0);
-    l_run += (lsum4[0] + lsum4[1]) + (lsum4[2] + lsum4[3]);
-  };
-
-  const int n_it = nt - 1;                        // iterations (tiles that have a successor)
-  const int n_plain = ragged ? n_it - 1 : n_it;   // ... whose successor is a full tile (a ragged tail is the last tile)
-  int t = 0;
-  for (; t + 1 < n_plain; t += 2) {  // two tiles per trip: the score blocks swap roles
-    iter(std::false_type{}, t, scA, scB);
-    iter(std::false_type{}, t + 1, scB, scA);
-  }
-  if (t < n_plain) {
-    iter(std::false_type{}, t, scA, scB);
-    ++t;
-    if (t < n_it) {
-      iter(std::true_type{}, t, scB, scA);
-      last(t + 1, scA);
-    } else {
-      last(t, scB);
-    }
-  } else if (t < n_it) {
-    iter(std::true_type{}, t, scA, scB);
-    last(t + 1, scB);
-  } else {
-    last(t, scA);
-  }
-#undef SEVA_SLOT_END
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  __syncthreads();  // every wave is done reading K/V tiles
-  char* const ow = smem + wave * (32 * 128);
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      half4_t h;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[db][4 * tt + r] * inv);
-      const int d0 = 32 * db + 8 * tt + 4 * hh;
-      const int chunk = d0 >> 3, piece = (d0 >> 2) & 1;
-      *(half4_t*)(ow + qi * 128 + ((chunk ^ (qi & 7)) << 4) + (piece << 3)) = h;
-    }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-  __builtin_amdgcn_wave_barrier();
-  const int q0 = qb * (32 * NW) + wave * 32;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * i + (lane >> 3), pchunk = lane & 7;
-    const uint4 v = *(const uint4*)(ow + row * 128 + (pchunk << 4));
-    const int lchunk = pchunk ^ (row & 7);
-    if (q0 + row < p.lq) *(uint4*)(obase + (int64_t)(q0 + row) * p.o_sl + lchunk * 8) = v;
-  }
-}
-#endif  // SEVA_EXPERIMENTAL
 
 template <int NW, int KT>
 int launch(const AttnArgs& a, int64_t batch, hipStream_t s, bool use_tr, bool pre) {
@@ -1211,18 +870,5 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
     hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
     return seva_check_launch("attn2_kernel");
   }
-#ifdef SEVA_EXPERIMENTAL
-  if (pre && use_tr && !a.dbg && two == 3 && d->lq >= 512) {  // software-pipelined kernel (experimental library only)
-    AttnArgs args = a;
-    args.qblocks = (a.lq + 127) / 128;
-    const int64_t nb = batch * a.heads * args.qblocks;
-    if (nb <= 0 || nb > 0x7fffffff) {
-      seva_set_error("attention: bad grid %lld", (long long)nb);
-      return SEVA_ERR_ARG;
-    }
-    hipLaunchKernelGGL((attn3_kernel<64, 4>), dim3((unsigned)nb), dim3(256), 0, s, args);
-    return seva_check_launch("attn3_kernel");
-  }
-#endif
   return launch<4, 64>(a, batch, s, use_tr, pre);
 }

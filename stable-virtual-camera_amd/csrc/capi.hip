@@ -32,13 +32,12 @@ struct KnobEntry {
 };
 const KnobEntry kKnobs[] = {
     {"gemm_chunks", "SEVA_GEMM_CHUNKS", &SevaKnobs::gemm_chunks}, {"gemm_dbg", "SEVA_GEMM_DBG", &SevaKnobs::gemm_dbg},
-    {"gemm_stagger", "SEVA_GEMM_STAGGER", &SevaKnobs::gemm_stagger}, {"gemm_cfg", "SEVA_GEMM_CFG", &SevaKnobs::gemm_cfg},
-    {"gemm_streamk", "SEVA_GEMM_STREAMK", &SevaKnobs::gemm_streamk},
+    {"gemm_stagger", "SEVA_GEMM_STAGGER", &SevaKnobs::gemm_stagger},
     {"gemm_bm", "SEVA_GEMM_BM", &SevaKnobs::gemm_bm}, {"gemm_bn", "SEVA_GEMM_BN", &SevaKnobs::gemm_bn},
     {"gemm_astat", "SEVA_GEMM_ASTAT", &SevaKnobs::gemm_astat}, {"attn_dbg", "SEVA_ATTN_DBG", &SevaKnobs::attn_dbg},
     {"attn_no_tr", "SEVA_ATTN_NO_TR", &SevaKnobs::attn_no_tr}, {"attn_two", "SEVA_ATTN_TWO", &SevaKnobs::attn_two},
     {"attn_split", "SEVA_ATTN_SPLIT", &SevaKnobs::attn_split},
-    {"gn_min_iter", "SEVA_GN_MIN_ITER", &SevaKnobs::gn_min_iter}, {"ff_variant", "SEVA_FF_VARIANT", &SevaKnobs::ff_variant},
+    {"gn_min_iter", "SEVA_GN_MIN_ITER", &SevaKnobs::gn_min_iter},
     {"conv_win", "SEVA_CONV_WIN", &SevaKnobs::conv_win},
 };
 SevaKnobs knobs_from_env() {

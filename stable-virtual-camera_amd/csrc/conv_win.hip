@@ -36,12 +36,17 @@ constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
 
 struct ConvWinGeom {
   uint32_t mul_hw, mul_iw, mul_sp, mul_wp;  // floor(2^32 / d) + 1: x / d == mulhi(x, mul) for x * d < 2^32 (host-checked)
-  int32_t Wp, Sp, hw;
+  int32_t Wp, Sp, hw;                       // hw = OUTPUT pixels per image; mul_iw divides by the OUTPUT width ow
+  int32_t ow;
   int32_t tiles_m, tiles_n;
   int32_t tpi;  // 0: M-tiles are consecutive BM-pixel ranges of the whole batch; > 0: tiles per image (a tile never leaves its image)
 };
 
-template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS>
+// UP: the conv input is the nearest-2x upsampled image (reference layers.py:35-46: F.interpolate(scale_factor=2) then conv): the window
+// is staged from the SOURCE image and tap (ky, kx) of output pixel (y, x) reads source pixel ((y + ky - 1) >> 1, (x + kx - 1) >> 1)
+// (A third weight stage with a counted vmcnt -- tap g + 2 issued under tap g, this tap's own DMA left in flight across the barrier -- was
+// built and measured on the 8-wave family: 3 - 10 % SLOWER on every shape, profiles/r04_kconvwin_variants.log; removed.)
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWinGeom g) {
   constexpr int WMW = NW / 2, WNW = 2;
   constexpr int WM = BM / WMW, WN = BN / WNW;  // per-wave tile
@@ -80,16 +85,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   }
   const int64_t n0 = (int64_t)tn * BN;
 
-  auto pad_index = [&](uint32_t m) -> uint32_t {
+  // padded index of the source pixel under the CENTRE tap of output pixel m (UP: of the pixel it is upsampled from); xo = its column
+  auto pad_index = [&](uint32_t m, uint32_t& yo, uint32_t& xo) -> uint32_t {
     const uint32_t img = __umulhi(m, g.mul_hw);
     const uint32_t rem = m - img * (uint32_t)g.hw;
-    const uint32_t y = __umulhi(rem, g.mul_iw);
-    const uint32_t x = rem - y * (uint32_t)p.iw;
+    yo = __umulhi(rem, g.mul_iw);
+    xo = rem - yo * (uint32_t)g.ow;
+    const uint32_t y = UP ? yo >> 1 : yo, x = UP ? xo >> 1 : xo;
     return img * (uint32_t)g.Sp + (y + 1) * (uint32_t)g.Wp + x + 1;
   };
-  const uint32_t P0 = pad_index(m0);
-  const uint32_t q0 = P0 - (uint32_t)(g.Wp + 1);                            // padded index of window pixel 0
-  const int WL = (int)(pad_index(m_end - 1) - P0) + 2 * (g.Wp + 1) + 1;     // window pixels this tile reads (<= WCAP)
+  uint32_t y_a, x_a, y_b, x_b;
+  const uint32_t P0 = pad_index(m0, y_a, x_a), P1 = pad_index(m_end - 1, y_b, x_b);
+  // window = [first source pixel any tap reads, last one]: plain conv: consecutive pixels, one halo of Wp + 1 on either side;
+  // UP: output rows 2r and 2r + 1 read the same source row, so the window holds whole source rows (first row's start .. last row's end)
+  const uint32_t q0 = (UP ? P0 - (x_a >> 1) : P0) - (uint32_t)(g.Wp + 1);   // padded index of window pixel 0
+  const int WL = (int)((UP ? P1 - (x_b >> 1) + (uint32_t)p.iw - 1 : P1) - q0) + g.Wp + 2;  // window pixels this tile reads (<= WCAP)
   const int npc = __builtin_amdgcn_readfirstlane((WL + 7) >> 3);
 
   // ---- window fill: lane (pixel 8 pc + sr, physical chunk sp) of piece pc fetches logical chunk sp ^ key(pixel) ----
@@ -145,12 +155,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
     const int rb = wn * WN + fr;
     b_off[s2] = rb * 128 + (((4 * s2 + fg) ^ ((rb >> 1) & 7)) << 4);
   }
-  int a_base[MI];  // window pixel of (row 16 i + fr of the wave's tile) at tap (0, 0)
+  // window pixel of row (16 i + fr) of the wave's tile: plain conv at tap (0, 0), the tap shift ky * Wp + kx is a uniform scalar;
+  // UP: at ky = 0 / 1 / 2 with kx = 1, plus the pixel's column parity (the kx shift is (xpar - 1, 0, xpar))
+  int a_base[MI], a_rm[UP ? MI : 1], a_rp[UP ? MI : 1], a_xp[UP ? MI : 1];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    uint32_t m = m0 + wm * WM + 16 * i + fr;
+    uint32_t m = m0 + wm * WM + 16 * i + fr, yo, xo;
     if (m >= m_end) m = m_end - 1;
-    a_base[i] = (int)(pad_index(m) - P0);
+    const int ctr = (int)(pad_index(m, yo, xo) - q0);
+    if constexpr (UP) {
+      const int yp = (int)(yo & 1), xp = (int)(xo & 1);
+      a_base[i] = ctr;
+      a_rm[i] = ctr + (yp - 1) * g.Wp;
+      a_rp[i] = ctr + yp * g.Wp;
+      a_xp[i] = xp;
+    } else {
+      a_base[i] = ctr - g.Wp - 1;
+    }
   }
 
   const int nslab = p.cin / BK;
@@ -187,26 +208,30 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
 #pragma unroll
     for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
 
-  int gk = 0;  // running K-tile index (parity = weight stage)
+  int cur = 0;  // weight stage of the K-tile being computed
   for (int s = 0; s < nslab; ++s) {
     const char* const win = lds_win + (DBW ? (s & 1) * WIN_BYTES : 0);
     const bool more = s + 1 < nslab;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int cur = gk & 1;
-      ++gk;
       if (t < 8) stage_w(cur ^ 1, (t + 1) * p.cin + BK * s);
       else if (more) stage_w(cur ^ 1, BK * (s + 1));
       if constexpr (DBW) {  // the next slab's window, one piece per wave and tap, into the other buffer
         if (more && t < PPW) fill_piece(t, s + 1, (s + 1) & 1);
       }
       const char* const tb = lds_b + cur * B_BYTES;
-      int toff = (t / 3) * g.Wp + (t % 3);
+      int toff = UP ? 0 : (t / 3) * g.Wp + (t % 3);
       asm volatile("" : "+s"(toff));  // opaque: the nine taps' fragment addresses are formed here, not hoisted out of the slab loop (45 registers)
       half8_t af[2][MI], bf[2][NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int j = a_base[i] + toff;
+        int j;
+        if constexpr (UP) {
+          const int ky = t / 3, kx = t % 3;  // compile-time after unrolling
+          j = (ky == 0 ? a_rm[i] : ky == 1 ? a_base[i] : a_rp[i]) + (kx == 0 ? a_xp[i] - 1 : kx == 1 ? 0 : a_xp[i]) + toff;
+        } else {
+          j = a_base[i] + toff;
+        }
         const int addr = j * 128 + ((fg ^ ((j >> 1) & 7)) << 4);
         af[0][i] = *(const half8_t*)(win + addr);
         af[1][i] = *(const half8_t*)(win + (addr ^ 64));
@@ -233,6 +258,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      cur ^= 1;
     }
   }
 
@@ -304,24 +330,32 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
 
 uint32_t magic_u32(uint32_t d) { return (uint32_t)(0x100000000ull / d) + 1u; }
 
-template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS>
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false>
 int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
   constexpr int lds = (DBW ? 2 : 1) * WCAP * 128 + 2 * BN * 128;
+  static_assert(lds <= 160 * 1024, "LDS per workgroup");
   static std::atomic<uint64_t> attr_devs{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
-    (void)hipFuncSetAttribute((const void*)conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_devs.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   ConvWinGeom g = g0;
   g.tiles_n = (int)((a.N + BN - 1) / BN);
   // the widest window any tile needs must fit the instantiation's capacity: consecutive pixels of the whole batch if that fits
   // (a tile may then straddle images), else consecutive pixels of one image, else the launch is not for this kernel
-  const auto pad_index = [&](int64_t m) {
-    const int64_t img = m / g.hw, rem = m % g.hw;
-    return img * g.Sp + (rem / a.iw + 1) * g.Wp + rem % a.iw + 1;
+  const auto window_len = [&](int64_t ma, int64_t mb) {  // the kernel's WL for output rows [ma, mb]
+    const auto idx = [&](int64_t m, int64_t& x) {
+      const int64_t img = m / g.hw, rem = m % g.hw, y = rem / g.ow;
+      x = rem % g.ow;
+      return img * g.Sp + ((UP ? y >> 1 : y) + 1) * g.Wp + (UP ? x >> 1 : x) + 1;
+    };
+    int64_t xa, xb;
+    const int64_t pa = idx(ma, xa), pb = idx(mb, xb);
+    const int64_t q0 = (UP ? pa - (xa >> 1) : pa) - (g.Wp + 1);
+    return (UP ? pb - (xb >> 1) + a.iw - 1 : pb) - q0 + g.Wp + 2;
   };
   const auto widest = [&](int tpi) {
     const int64_t tiles = tpi > 0 ? (int64_t)tpi : (a.M + BM - 1) / BM;  // per-image tiling: every image has the same windows
@@ -329,7 +363,7 @@ int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
     for (int64_t t = 0; t < tiles; ++t) {
       const int64_t lim = tpi > 0 ? g.hw : a.M;
       const int64_t ma = t * BM, mb = ma + BM < lim ? ma + BM : lim;
-      const int64_t wl = pad_index(mb - 1) - pad_index(ma) + 2 * (g.Wp + 1) + 1;
+      const int64_t wl = window_len(ma, mb - 1);
       if (wl > wl_max) wl_max = wl;
     }
     return wl_max;
@@ -349,7 +383,7 @@ int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
     seva_set_error("conv_win: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  hipLaunchKernelGGL((conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS>), dim3((unsigned)nb), dim3(64 * NW), lds, s, a, g);
+  hipLaunchKernelGGL((conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP>), dim3((unsigned)nb), dim3(64 * NW), lds, s, a, g);
   return seva_check_launch("conv_win_kernel");
 }
 
@@ -359,22 +393,33 @@ int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
 int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
   const int knob = g_seva_knobs.conv_win;
   if (knob == 0) return 1;
-  if (a.stride != 1 || a.upsample || a.pad_lo != 1 || a.a2 != nullptr || a.sk_ws != nullptr) return 1;
-  if (a.oh != a.ih || a.ow != a.iw || a.iw < 2 || a.ih < 2) return 1;
+  if (a.stride != 1 || a.pad_lo != 1 || a.a2 != nullptr || a.sk_ws != nullptr) return 1;
+  const int up = a.upsample ? 2 : 1;
+  if (a.oh != up * a.ih || a.ow != up * a.iw || a.iw < 2 || a.ih < 2) return 1;
   if (a.cin % 64 != 0 || a.N % 160 != 0 || a.K != 9LL * a.cin) return 1;
   ConvWinGeom g{};
-  g.Wp = a.iw + 1;
+  g.Wp = a.iw + 1;             // padded SOURCE space (UP: the image before the nearest-2x upsample)
   g.Sp = (a.ih + 1) * g.Wp;
-  g.hw = a.ih * a.iw;
+  g.hw = a.oh * a.ow;
+  g.ow = a.ow;
   // exactness of the multiply-high divisions (x * d < 2^32) and 31-bit byte offsets into the image
   const uint64_t q_max = (uint64_t)a.n * g.Sp + 1024;
   if (q_max * (uint64_t)g.Sp >= (1ull << 32) || (uint64_t)a.M * (uint64_t)g.hw >= (1ull << 32)) return 1;
-  if ((uint64_t)a.n * g.hw * a.cin * 2 >= (1ull << 31)) return 1;
+  if ((uint64_t)a.n * a.ih * a.iw * a.cin * 2 >= (1ull << 31)) return 1;
   g.mul_hw = magic_u32((uint32_t)g.hw);
-  g.mul_iw = magic_u32((uint32_t)a.iw);
+  g.mul_iw = magic_u32((uint32_t)g.ow);
   g.mul_sp = magic_u32((uint32_t)g.Sp);
   g.mul_wp = magic_u32((uint32_t)g.Wp);
   const bool stats = a.ch_stats != nullptr;
+  if (a.upsample) {
+    // fused nearest-2x upsample (the three Upsample convs of a step): the window over the SOURCE image is small (a quarter of the pixels),
+    // the 8-wave 256-row tile always fits; the 4-wave family serves launches too small to fill the CUs with 256-row tiles
+    const double t8 = (double)((a.M + 255) / 256) * (double)((a.N + 159) / 160);
+    const bool eight = knob == 2 || (knob != 1 && t8 >= 256.0);
+    int rc = eight ? launch_win<256, 160, 8, 416, true, true, true>(a, g, s) : launch_win<128, 160, 4, 288, false, true, true>(a, g, s);
+    if (rc == 1) rc = eight ? launch_win<128, 160, 4, 288, false, true, true>(a, g, s) : launch_win<256, 160, 8, 416, true, true, true>(a, g, s);
+    return rc;
+  }
   // Two instantiation families, bitwise equal to each other (same reduction order): two 4-wave workgroups per CU on 160-row tiles
   // (128 with statistics) or one 8-wave workgroup on a 256-row tile with the window double-buffered.  The 8-wave tile moves a third
   // fewer LDS-DMA bytes per FLOP and is ~5 % faster where its tile count fills whole rounds of the 256 CUs; the choice is made from

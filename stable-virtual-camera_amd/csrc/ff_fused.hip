@@ -50,213 +50,6 @@ __device__ __forceinline__ void ff_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-#ifdef SEVA_EXPERIMENTAL  // 4-wave variant: experimental library only (knob ff_variant = 4); the 8-wave kernel below is the product
-template <int C>
-__global__ __launch_bounds__(256, 1) void ff_fused_kernel(FfArgs p) {
-  static_assert(C % 64 == 0 && C <= 320, "C must be a multiple of 64, at most 320");
-  constexpr int KS = C / 32;         // k-steps of stage 1 held in registers
-  constexpr int NK1 = C / 64;        // W1 K-tiles (128-byte LDS rows) per hidden chunk
-  constexpr int NJ2 = C / 16;        // 16-feature output blocks
-  constexpr int NCH = C / 16;        // hidden chunks of 64 features (4C / 64)
-  constexpr int W1_BYTES = 128 * 128;  // one W1 K-tile: 128 rows x 128 B
-  constexpr int W2_BYTES = C * 128;    // one W2 slice: C rows x 64 hidden columns
-  constexpr int W2_PASSES = C / 32;    // 8-row wave-instructions per wave and slice (C/4 rows per wave)
-  constexpr int W2_PER_KT = (W2_PASSES + NK1 - 1) / NK1;  // spread over the chunk's K-tiles
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [W1 buf0][W1 buf1][W2 buf0][W2 buf1][b1: 8C floats]
-  char* const lds_w1 = smem;
-  char* const lds_w2 = smem + 2 * W1_BYTES;
-  float* const lds_b1 = (float*)(smem + 2 * W1_BYTES + 2 * W2_BYTES);
-  const unsigned lds_base_u32 = __builtin_amdgcn_readfirstlane(lds_addr_u32(smem));
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int fr = lane & 15, fg = lane >> 4;
-  const int sr = lane >> 3, sp = lane & 7;  // staging: row inside an 8-row pass, physical 16-byte chunk
-
-  const int tm = xcd_remap(blockIdx.x, p.tiles_m);
-  const int64_t m0 = (int64_t)tm * 128 + wave * 32;  // this wave's first token row
-
-  // ---- A fragments (MFMA B-operand layout: lane (fr, fg) holds row fr, k = 32*ks + 8*fg .. +7) ----
-  half8_t areg[2][KS];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int64_t m = m0 + 16 * i + fr;
-    if (m >= p.M) m = p.M - 1;
-    const half_t* ap = p.a + m * p.lda + 8 * fg;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) areg[i][ks] = *(const half8_t*)(ap + 32 * ks);
-  }
-  // ---- stage-2 accumulators start from the residual tile (lane: token 16i + fr, features 16jb + 4fg .. +3) ----
-  f32x4 acc2[2][NJ2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int64_t m = m0 + 16 * i + fr;
-    if (m >= p.M) m = p.M - 1;
-#pragma unroll
-    for (int jb = 0; jb < NJ2; ++jb)
-      acc2[i][jb] = p.residual ? *(const f32x4*)(p.residual + m * p.ldr + 16 * jb + 4 * fg) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // the whole GEGLU bias (8C floats) goes to LDS once: no compiler-visible global load inside the pipelined loop
-  for (int i = threadIdx.x; i < 2 * C; i += 256) *(f32x4*)(lds_b1 + 4 * i) = *(const f32x4*)(p.b1 + 4 * i);
-  // retire every compiler-visible load before the LDS-DMA pipeline starts (its waits are counted by hand)
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(areg[i][ks]));
-#pragma unroll
-    for (int jb = 0; jb < NJ2; ++jb) asm volatile("" : "+v"(acc2[i][jb]));
-  }
-
-  // ---- staging addresses ----
-  // W1 tile (128 rows): wave w stages rows 32w .. 32w+31 in 4 passes of 8 rows; chunk swizzle key of gemm.hip's paired rows
-  auto w1_key = [](int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); };
-  const half_t* w1_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + 8 * i + sr;
-    w1_src[i] = p.w1 + (int64_t)row * C + (sp ^ w1_key(row)) * 8;  // + chunk * 128 * C + kt * 64
-  }
-  // W2 slice (C rows x 128 B): wave w stages rows (C/4)w .. in W2_PASSES passes; natural key (row >> 1) & 7
-  // (passes 16 rows apart share the key: two base pointers + a constant row stride instead of one pointer per pass)
-  static_assert((C / 4) % 16 == 0, "a wave's W2 row range must start on a multiple of 16");
-  const half_t* w2_src[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * (C / 4) + 8 * i + sr;
-    w2_src[i] = p.w2 + (int64_t)row * (4 * C) + (sp ^ ((row >> 1) & 7)) * 8;  // + (i >> 1) * 16 rows + chunk * 64
-  }
-  auto stage_w1 = [&](int buf, int hc, int kt) {
-    const unsigned dst = lds_base_u32 + buf * W1_BYTES + wave * 32 * 128;
-    const int64_t off = (int64_t)hc * 128 * C + kt * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16_raw(w1_src[i] + off, dst + i * 1024);
-  };
-  auto stage_w2_part = [&](int buf, int hc, int part) {  // passes [part * W2_PER_KT, +W2_PER_KT)
-    const unsigned dst = lds_base_u32 + 2 * W1_BYTES + buf * W2_BYTES + wave * (C / 4) * 128;
-#pragma unroll
-    for (int u = 0; u < W2_PER_KT; ++u) {
-      const int i = part * W2_PER_KT + u;
-      if (i < W2_PASSES) glds16_raw(w2_src[i & 1] + (int64_t)(i >> 1) * 16 * (4 * C) + hc * 64, dst + i * 1024);
-    }
-  };
-  auto barrier_raw = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-
-  // ---- fragment-read offsets ----
-  int w1_off[2];  // stage 1: paired rows, block j adds (32*(j>>1) + 4*(j&1)) rows
-  int w2_off[2];  // stage 2: row 16jb + fr, k-step q -> chunk 4q + fg
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int rb = 8 * (fr >> 2) + (fr & 3);
-    w1_off[s] = rb * 128 + (((4 * s + fg) ^ w1_key(rb)) << 4);
-    w2_off[s] = fr * 128 + (((4 * s + fg) ^ ((fr >> 1) & 7)) << 4);  // rows 16 apart share the key
-  }
-
-  // ---- pipeline prologue: W1 tile (chunk 0, kt 0) and the whole W2 slice of chunk 0 ----
-  __syncthreads();  // b1 in LDS; nothing of this wave's global traffic is pending
-  stage_w1(0, 0, 0);
-#pragma unroll
-  for (int part = 0; part < NK1; ++part) stage_w2_part(0, 0, part);
-  ff_wait_vm<0>();
-  barrier_raw();
-
-  int cur = 0;  // W1 ring position
-  for (int hc = 0; hc < NCH; ++hc) {
-    f32x4 acc1[2][8];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---------------- stage 1: acc1 = W1[chunk] . a  ----------------
-#pragma unroll
-    for (int kt = 0; kt < NK1; ++kt) {
-      // next W1 tile into the other buffer, and a share of the NEXT chunk's W2 slice into the other W2 buffer
-      const bool last_kt = kt + 1 == NK1;
-      if (!last_kt) stage_w1(cur ^ 1, hc, kt + 1);
-      else if (hc + 1 < NCH) stage_w1(cur ^ 1, hc + 1, 0);
-      if (hc + 1 < NCH) stage_w2_part((hc + 1) & 1, hc + 1, kt);
-      const char* const tb = lds_w1 + cur * W1_BYTES;
-      half8_t bfr[2][8];
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bfr[s][j] = *(const half8_t*)(tb + w1_off[s] + (32 * (j >> 1) + 4 * (j & 1)) * 128);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[s][j], areg[i][2 * kt + s], acc1[i][j], 0, 0, 0);
-      ff_wait_vm<0>();  // the tile(s) issued above have landed
-      barrier_raw();    // ... for every wave; and everyone is done reading `cur`
-      cur ^= 1;
-    }
-
-    // ---------------- GEGLU in registers -> stage-2 B fragments ----------------
-    // bias of this chunk's 128 interleaved rows, out of LDS only now (32 registers that stage 1 does not have to carry) (value / gate of the lane's 8 features per 32-feature group)
-    f32x4 b1v[2][2], b1g[2][2];  // [group q][e]
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float* bp = lds_b1 + hc * 128 + 64 * q + 8 * fg + 4 * e;
-        b1v[q][e] = first_read(*(const f32x4*)bp);
-        b1g[q][e] = first_read(*(const f32x4*)(bp + 32));
-      }
-
-    half8_t hfrag[2][2];  // [token block i][32-feature group q]: features 32q + 8fg .. +7 of the chunk
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x4 o0 = geglu4(acc1[i][4 * q + 0] + b1v[q][0], acc1[i][4 * q + 2] + b1g[q][0]);
-        const f32x4 o1 = geglu4(acc1[i][4 * q + 1] + b1v[q][1], acc1[i][4 * q + 3] + b1g[q][1]);
-        hfrag[i][q] = half8_t{(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3],
-                              (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
-      }
-
-    // ---------------- stage 2: acc2 += W2[:, chunk] . h ----------------
-    const char* const t2 = lds_w2 + (hc & 1) * W2_BYTES;
-#pragma unroll
-    for (int jb = 0; jb < NJ2; ++jb) {
-      const half8_t w0 = *(const half8_t*)(t2 + w2_off[0] + jb * (16 * 128));
-      const half8_t w1f = *(const half8_t*)(t2 + w2_off[1] + jb * (16 * 128));
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        acc2[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, hfrag[i][0], acc2[i][jb], 0, 0, 0);
-        acc2[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f, hfrag[i][1], acc2[i][jb], 0, 0, 0);
-      }
-    }
-    // W2 buffer (hc & 1) is refilled (for chunk hc + 2) from the first K-tile of chunk hc + 1 on: every wave must have
-    // left this stage 2 before any wave issues that DMA
-    barrier_raw();
-  }
-
-  // ---------------- epilogue: + b2, stores ----------------
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int64_t m = m0 + 16 * i + fr;
-    const bool ok = m < p.M;
-#pragma unroll
-    for (int jb = 0; jb < NJ2; ++jb) {
-      const int f = 16 * jb + 4 * fg;
-      const f32x4 v = acc2[i][jb] + first_read(*(const f32x4*)(p.b2 + f));
-      if (!ok) continue;
-      if (p.out_f32) *(f32x4*)(p.out_f32 + m * p.ldo32 + f) = v;
-      if (p.out_f16) {
-        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *(half4_t*)(p.out_f16 + m * p.ldo16 + f) = h;
-      }
-    }
-  }
-}
-#endif  // SEVA_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------------------------------------------
 // 8-wave variant: the same 128-row tile, but TWO waves per 32-row group (2 waves per SIMD -> one wave's LDS / barrier waits
@@ -525,22 +318,6 @@ __global__ __launch_bounds__(512, 2) void ff_fused8_kernel(FfArgs p) {
   }
 }
 
-#ifdef SEVA_EXPERIMENTAL
-template <int C>
-int ff_launch(const FfArgs& a, hipStream_t s) {
-  constexpr int lds = 2 * 128 * 128 + 2 * C * 128 + 8 * C * 4;
-  static std::atomic<uint64_t> attr_devs{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
-    (void)hipFuncSetAttribute((const void*)ff_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_devs.fetch_or(bit, std::memory_order_relaxed);
-  }
-  hipLaunchKernelGGL((ff_fused_kernel<C>), dim3((unsigned)a.tiles_m), dim3(256), lds, s, a);
-  return seva_check_launch("ff_fused_kernel");
-}
-#endif
 
 template <int C>
 int ff_launch8(const FfArgs& a, hipStream_t s) {
@@ -588,16 +365,6 @@ extern "C" int seva_ff_fused_f16(const seva_ff_desc* d, seva_stream_t stream) {
   const double bytes = (double)d->M * C * ((d->ln_x ? 4.0 : 2.0) + (d->residual ? 4.0 : 0.0) + (d->out_f32 ? 4.0 : 0.0) + (d->out_f16 ? 2.0 : 0.0)) +
                        2.0 * (8.0 * C * C + 4.0 * C * C);
   SevaProfScope prof(0, flops, s, bytes);
-#ifdef SEVA_EXPERIMENTAL
-  if (g_seva_knobs.ff_variant == 4 && !d->ln_x) {  // knob ff_variant = 4: the 4-wave kernel (benchmarking); default: 8 waves
-    switch (d->C) {
-      case 64: return ff_launch<64>(a, s);
-      case 128: return ff_launch<128>(a, s);
-      case 256: return ff_launch<256>(a, s);
-      default: return ff_launch<320>(a, s);
-    }
-  }
-#endif
   switch (d->C) {
     case 64: return ff_launch8<64>(a, s);
     case 128: return ff_launch8<128>(a, s);

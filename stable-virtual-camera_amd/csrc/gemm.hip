@@ -1015,14 +1015,6 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     if (half_m8) return wide8 ? launch<64, 160, 1, 0, true>(a, s) : launch<64, 128, 1, 0, true>(a, s);
     return launch<128, 128, 1, 0, true>(a, s);
   } else {
-#ifdef SEVA_EXPERIMENTAL
-  // experimental library only (make exp -> build_ab/libseva_hip_exp.so, loaded through SEVA_HIP_LIB for A/B runs): knob
-  // gemm_cfg = 1/2/3 (ring variants, gemm_ring.hip), 4 (256x256 phased, gemm_phase.hip).  None of them wins on any shape of
-  // this network, so the production library does not carry them.
-  const int cfg = g_seva_knobs.gemm_cfg;
-  if (cfg == 4 && !narrow) return seva_gemm_phase_launch(a, d->mode, d->epilogue, s);
-  if (cfg > 0 && !narrow) return seva_gemm_ring_launch(a, d->mode, d->epilogue, cfg, s);
-#endif
   // Small problems (the ds8 level: 27 x 8 tiles of 128 rows on 512 workgroup slots) get 64-row tiles: twice the
   // workgroups, both slots of a CU busy.  SEVA_GEMM_BM=64|128 forces the height (benchmark knob).
   bool half_m = ((d->M + 127) / 128) * ((d->N + 159) / 160) < 320 && d->M > 64;
@@ -1070,26 +1062,6 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   // 5-25 % slower: profiles/r01_kbench_bn64.log.)  SEVA_GEMM_BN=128|160 forces the width (benchmark knob).
   bool wide = d->N % 160 == 0;
   if (g_seva_knobs.gemm_bn > 0) wide = g_seva_knobs.gemm_bn == 160;
-#ifdef SEVA_EXPERIMENTAL  // stream-K lives in the experimental library only (knob gemm_streamk = 1): slower on every shape
-  // Stream-K (gemm_sk.hip) for fp32-output launches whose 128-row tile count leaves the last round of the 512 workgroup slots
-  // partly empty (18 x 18 level: 856 tiles = 1.67 rounds).  Bitwise equal to the unsplit kernel -- and SLOWER on every shape of
-  // this network (-1 ... -23 %, tools/kstreamk.py): equal K-ranges desynchronise the sibling tiles that otherwise stream one A
-  // panel through an XCD's L2 in step, and that costs more than the partly empty round.  Opt-in only (knob gemm_streamk = 1).
-  if (d->splitk_ws && !a.sk_ws && !half_m && !narrow && d->out_f32 && d->col_scale_n == 0 && !d->upsample &&
-      g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_chunks <= 0 && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0 &&
-      g_seva_knobs.gemm_cfg <= 0 && g_seva_knobs.gemm_streamk != 0) {
-    const int bn = wide ? 160 : 128, P = 512;
-    const int64_t tm = (d->M + 127) / 128, tn = (d->N + bn - 1) / bn, T = tm * tn, rem = T % P;
-    (void)rem;
-    if (g_seva_knobs.gemm_streamk == 1 && T >= P && a.K / BK >= 8 &&
-        d->splitk_ws_bytes >= (int64_t)(16384 + (int64_t)P * 128 * bn) * 4 && (uintptr_t)d->splitk_ws % 16 == 0) {
-      a.sk_ws = d->splitk_ws;
-      a.tiles_m = (int)tm;
-      a.tiles_n = (int)tn;
-      return seva_gemm_streamk_launch(a, d->mode, bn, P, s);
-    }
-  }
-#endif  // SEVA_EXPERIMENTAL
   // 160 x 160 tiles for the fp32-output kernels (not the f16-only ASYNC ones: their bias slots would not fit): 0.0125 operand bytes
   // per FLOP instead of 0.0141, 50 instead of 40 MFMAs per wave and barrier; two workgroups take EXACTLY the CU's 160 KiB of LDS
   // and all 256 registers (no spill in GEMM mode, 7 dwords in conv mode).  Bitwise the same outputs; -3 ... -10 % on every shape
@@ -1098,15 +1070,6 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   {
     const bool dbg_run = g_seva_knobs.gemm_dbg >= 0 || g_seva_knobs.gemm_stagger >= 0;
     const bool f16_only = d->mode == 0 && d->out_f16 && !d->out_f32 && !d->residual;
-#ifdef SEVA_EXPERIMENTAL
-    // 8-wave 128 x 320 tiles (knob gemm_bn = 320; experimental library only): one workgroup per CU whose two halves share the
-    // staged A rows.  Bitwise equal (statistics included) and 13-23 % fewer operand bytes per FLOP -- and 15-30 % SLOWER on the
-    // GEMMs, level on the convs (tools/ktile320.py, profiles/r02_ktile320.log): one 8-wave barrier domain per CU loses more than
-    // the shared A rows return.
-    if (g_seva_knobs.gemm_bn == 320 && d->N % 320 == 0 && !dbg_run && !d->upsample && !a.sk_ws && !f16_only && d->out_f32)
-      return d->mode == 0 ? launch_p<128, 320, 0, 0, false, false, false, false, 8>(a, s)
-                          : launch_p<128, 320, 1, 0, false, false, false, false, 8>(a, s);
-#endif
     const bool big = g_seva_knobs.gemm_bm == 160 ||
                      (g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0 && !dbg_run && !half_m && d->M >= 2048);
     if (big && wide && !narrow && !d->ch_stats && !d->upsample && !a.sk_ws && !f16_only) {

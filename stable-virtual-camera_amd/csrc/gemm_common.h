@@ -106,10 +106,3 @@ static __device__ __forceinline__ float row16_sum(float v) {
 
 // conv_win.hip: 3x3 / stride 1 / pad 1 conv with the tile's input window staged in LDS.  0 = launched, 1 = not applicable, < 0 = error
 int seva_conv_win_launch(const GemmArgs& a, hipStream_t s);
-
-// gemm_sk.hip: stream-K variant of the plain f32-output kernel (a.tiles_m / a.tiles_n for 128 x bn tiles, a.sk_ws set)
-int seva_gemm_streamk_launch(const GemmArgs& a, int mode, int bn, int nblocks, hipStream_t s);
-// gemm_ring.hip: cfg 1 = 256x128x64 (3 stages), cfg 2 = 256x256x32 (4 stages), cfg 3 = 128x128x32 (4 stages)
-int seva_gemm_ring_launch(const GemmArgs& a, int mode, int epilogue, int cfg, hipStream_t s);
-// gemm_phase.hip: 256x256x64, two wave groups in anti-phase (cfg 4)
-int seva_gemm_phase_launch(const GemmArgs& a, int mode, int epilogue, hipStream_t s);

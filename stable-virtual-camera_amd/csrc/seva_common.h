@@ -32,10 +32,9 @@ int seva_check_launch(const char* what);
 // Benchmark / debugging knobs (capi.hip).  Read ONCE from the SEVA_* environment when the library is loaded (no
 // getenv on the launch path); tests and tools change them at run time through seva_set_knob().  -1 = unset.
 struct SevaKnobs {
-  int gemm_chunks, gemm_dbg, gemm_stagger, gemm_cfg, gemm_bm, gemm_bn, gemm_astat, gemm_streamk;
+  int gemm_chunks, gemm_dbg, gemm_stagger, gemm_bm, gemm_bn, gemm_astat;
   int attn_dbg, attn_no_tr, attn_two, attn_split;
   int gn_min_iter;
-  int ff_variant;
   int conv_win;  // 0: per-tap gather everywhere; 1: window kernel, two 4-wave workgroups per CU; 2: 8-wave 256-row tile; unset: default
 };
 extern SevaKnobs g_seva_knobs;

@@ -309,8 +309,7 @@ class SevaEngine:
 
     def _sk(self, rows=0, hw=0, c=0):
         """Workspace of seva_gemm_desc.splitk_ws (one per engine; its launches are serialised on one stream): lets the library run
-        the convs of small images (the 9x9 level) as split-K (and, under the knob gemm_streamk = 1, the convs of the 18x18 / 36x36 levels
-        as stream-K: measured slower).  16384 flags + 512 slots of 128 x 160 floats (>= every split-K need here)."""
+        the convs of small images (the 9x9 level) as split-K.  16384 flags + one 128 x 160 fp32 slot per output tile (>= 512)."""
         if not self.conv_splitk:
             return None
         # sized from the launch (never below 512 slots), so that whether a small-image conv is split depends on the per-sample

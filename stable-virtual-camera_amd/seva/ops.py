@@ -43,7 +43,7 @@ def gemm(
     splitk_ws: torch.Tensor | None = None,
 ) -> None:
     """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16).
-    splitk_ws (`splitk_workspace`): lets fp32-output launches with a partly filled last round of workgroup slots run as stream-K.
+    splitk_ws (`splitk_workspace`): only convolutions use it (seva_gemm_desc.splitk_ws); accepted and ignored for plain GEMMs.
     ch_stats (`channel_stats_buffer`): receives per-64-row-block, per-channel sum / sum of squares of out_f32 (GroupNorm
     statistics emitted by the epilogue; `groupnorm(stats1=...)`).
     Output features < col_scale_n are multiplied by col_scale in fp32 (plain epilogue only).
@@ -129,7 +129,7 @@ def check_handoffs() -> None:
 
 def splitk_workspace(max_rows: int, max_channels: int, device) -> torch.Tensor:
     """Zeroed workspace for `conv3x3(splitk_ws=...)`: 16384 flags + one fp32 128 x 160 tile per output tile."""
-    tiles = max(512, ((max_rows + 127) // 128) * ((max_channels + 127) // 128))  # (stream-K: one slot per workgroup, 512 of them)
+    tiles = max(512, ((max_rows + 127) // 128) * ((max_channels + 127) // 128))
     return torch.zeros(16384 + tiles * 128 * 160, dtype=F32, device=device)
 
 

@@ -42,8 +42,8 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-KNOB_NAMES = ("gemm_chunks", "gemm_dbg", "gemm_stagger", "gemm_cfg", "gemm_bm", "gemm_bn", "gemm_astat", "gemm_streamk",
-              "attn_dbg", "attn_no_tr", "attn_two", "attn_split", "gn_min_iter", "ff_variant", "conv_win")
+KNOB_NAMES = ("gemm_chunks", "gemm_dbg", "gemm_stagger", "gemm_bm", "gemm_bn", "gemm_astat",
+              "attn_dbg", "attn_no_tr", "attn_two", "attn_split", "gn_min_iter", "conv_win")
 
 
 @pytest.fixture

@@ -116,37 +116,6 @@ def test_geglu_multi_tile_walk(dev, M, C, K, astat, knobs):
     assert torch.isfinite(o16).all() and rel_l2(o16, ref) < 1e-3
 
 
-def _need_exp_lib(what):
-    """Kernels that lost their A/B live only in build_ab/libseva_hip_exp.so (`make -C stable-virtual-camera_amd/csrc exp`,
-    loaded through SEVA_HIP_LIB): skipped against the production library, which does not carry them."""
-    if "exp" not in os.path.basename(os.environ.get("SEVA_HIP_LIB", "")):
-        pytest.skip(f"production libseva_hip.so does not carry {what} (experimental library only)")
-
-
-@pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
-@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 4, 64), (777, 960, 640), (4097, 132, 192)])
-def test_gemm_experimental_kernels_exact(dev, M, N, K, cfg, knobs):
-    """The ring (cfg 1-3) and phased (cfg 4) GEMM kernels live in the EXPERIMENTAL library only
-    (`make -C stable-virtual-camera_amd/csrc exp`, loaded with SEVA_HIP_LIB=build_ab/libseva_hip_exp.so); there they
-    stay bit-exact with the default kernel.  Skipped against the production library, which does not carry them."""
-    from seva import ops
-    if "exp" not in os.path.basename(os.environ.get("SEVA_HIP_LIB", "")):
-        pytest.skip("production libseva_hip.so carries no experimental GEMM kernels")
-    knobs(gemm_cfg=cfg)
-    a, w = _ints((M, K), -4, 4, dev, 1), _ints((N, K), -3, 3, dev, 2)
-    bias, res = _ints((N,), -5, 5, dev, 3), _ints((M, N), -9, 9, dev, 4)
-    o32 = torch.full((M, N), float("nan"), device=dev)
-    ops.gemm(a.half(), w.half(), bias=bias, residual=res, out_f32=o32)
-    assert torch.equal(o32, a @ w.T + bias + res)
-    x = _ints((2, 64, 9, 7), -3, 3, dev, 5)
-    wc = _ints((96, 64, 3, 3), -2, 2, dev, 6)
-    from seva._engine import pack_conv3x3
-    out = torch.full((2, 63, 96), float("nan"), device=dev)
-    ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(wc), out_f32=out)
-    ref = F.conv2d(x, wc, None, padding=1)
-    assert torch.equal(out.view(2, 9, 7, 96).permute(0, 3, 1, 2), ref)
-
-
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (2049, 1280, 1280)])
 def test_gemm_random(dev, M, N, K):
     from seva import ops
@@ -231,34 +200,40 @@ def test_tile_160x160_bitwise_equal(dev, kind, shape, knobs):
         assert torch.equal(o, outs[0])
 
 
-WIN_CASES = [  # n, ih, iw, cin, cout, statistics
-    (42, 18, 18, 128, 320, False), (5, 36, 36, 64, 640, False), (2, 72, 72, 64, 320, True), (3, 9, 9, 128, 160, False),
-    (5, 7, 11, 64, 320, False), (1, 33, 31, 192, 160, False), (2, 16, 16, 64, 160, True), (7, 5, 4, 128, 320, False),
-    (4, 24, 40, 128, 480, False), (3, 8, 8, 64, 160, True),
+WIN_CASES = [  # n, ih, iw, cin, cout, statistics, fused nearest-2x upsample
+    (42, 18, 18, 128, 320, False, False), (5, 36, 36, 64, 640, False, False), (2, 72, 72, 64, 320, True, False), (3, 9, 9, 128, 160, False, False),
+    (5, 7, 11, 64, 320, False, False), (1, 33, 31, 192, 160, False, False), (2, 16, 16, 64, 160, True, False), (7, 5, 4, 128, 320, False, False),
+    (4, 24, 40, 128, 480, False, False), (3, 8, 8, 64, 160, True, False),
+    (42, 9, 9, 128, 320, False, True), (3, 18, 18, 64, 160, True, True), (2, 36, 36, 64, 320, True, True), (5, 7, 5, 128, 160, False, True),
+    (1, 16, 24, 192, 320, True, True),
 ]
 
 
-@pytest.mark.parametrize("n,ih,iw,cin,cout,stats", WIN_CASES)
-def test_conv3x3_window_kernel(dev, n, ih, iw, cin, cout, stats, knobs):
+@pytest.mark.parametrize("n,ih,iw,cin,cout,stats,up", WIN_CASES)
+def test_conv3x3_window_kernel(dev, n, ih, iw, cin, cout, stats, up, knobs):
     """csrc/conv_win.hip (reference convs: seva/modules/layers.py:101,113): the tile's input window + halo staged in LDS once per
     64-channel slab, nine taps from shifted fragment addresses.  Integer data: bit-exact against torch for both instantiation
     families (two 4-wave workgroups per CU / one 8-wave 256-row tile), with bias + row_add + residual and epilogue-emitted
     GroupNorm statistics; tiles that straddle images (18 x 18, 9 x 9, 5 x 4), per-image tiling (72 x 72), M tails, windows
     cut by the end of the batch.  Random data: the two families agree bit for bit (same reduction order) and differ from the
-    per-tap kernel only by the order of the fp32 additions (slab-outer instead of tap-outer)."""
+    per-tap kernel only by the order of the fp32 additions (slab-outer instead of tap-outer).  `up`: the fused nearest-2x upsample
+    (reference layers.py:35-46): the window is staged from the SOURCE image, tap (ky, kx) of output pixel (y, x) reads source pixel
+    ((y + ky - 1) >> 1, (x + kx - 1) >> 1)."""
     from seva import ops
     from seva._engine import pack_conv3x3
-    M, hw = n * ih * iw, ih * iw
+    sc = 2 if up else 1
+    M, hw = n * ih * iw * sc * sc, ih * iw * sc * sc
     x = _ints((n, cin, ih, iw), -3, 3, dev, 1)
     w = _ints((cout, cin, 3, 3), -2, 2, dev, 2)
     bias, emb, res = _ints((cout,), -4, 4, dev, 3), _ints((n, cout), -2, 2, dev, 4), _ints((n, hw, cout), -5, 5, dev, 5)
-    ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1).reshape(n, hw, cout) + emb[:, None, :] + res
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, bias, padding=1).permute(0, 2, 3, 1).reshape(n, hw, cout) + emb[:, None, :] + res
     xh, wp = x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w)
     for fam in (1, 2):
         knobs(conv_win=fam)
         out = torch.full((n, hw, cout), float("nan"), device=dev)
         st = torch.full(ops.channel_stats_shape(M, cout), float("nan"), device=dev) if stats else None
-        ops.conv3x3(xh, wp, bias=bias, row_add=emb, rows_per_group=hw, residual=res, out_f32=out, ch_stats=st)
+        ops.conv3x3(xh, wp, upsample=up, bias=bias, row_add=emb, rows_per_group=hw, residual=res, out_f32=out, ch_stats=st)
         assert torch.equal(out, ref), f"family {fam}: max diff {(out - ref).abs().max()}"
         if st is not None:
             assert torch.equal(st.double(), _block_stats(out.view(M, cout), M, cout))
@@ -268,7 +243,7 @@ def test_conv3x3_window_kernel(dev, n, ih, iw, cin, cout, stats, knobs):
     for fam in (0, 1, 2):
         knobs(conv_win=fam)
         o = torch.full((n, hw, cout), float("nan"), device=dev)
-        ops.conv3x3(xr, wr, bias=bias, residual=rr, out_f32=o)
+        ops.conv3x3(xr, wr, upsample=up, bias=bias, residual=rr, out_f32=o)
         outs.append(o)
     assert torch.equal(outs[1], outs[2])
     assert rel_l2(outs[1], outs[0]) < 3e-6
@@ -351,16 +326,14 @@ QK_C = 0.125 * 1.4426950408889634
 @pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 200, 200), (1, 1, 1701, 1701), (2, 3, 70, 5), (4, 2, 21, 21),
                                        (1, 2, 33, 64), (2, 1, 500, 777), (2, 2, 1024, 900), (1, 3, 777, 1300)])
 @pytest.mark.parametrize("spike", [False, True])
-@pytest.mark.parametrize("two", ["0", "1", "3"])
+@pytest.mark.parametrize("two", ["0", "1"])
 def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, knobs):
     """q already multiplied by scale*log2(e) (what the engine's QKV projection emits): the kernel starts
     its score accumulators at -m_run and exponentiates the MFMA output directly.  `spike` plants, late in
     the key sequence, keys that beat the running maximum by far more than the deferred-rescale threshold
     (rescale branch), and shifts all logits of the first tile far below zero (first-tile reference)."""
     from seva import ops
-    if two == "3":
-        _need_exp_lib("the software-pipelined attention kernel")
-    knobs(attn_two=two)  # 0: attn_kernel everywhere, 1: the two-query-block kernel from Lq >= 512, 3: the software-pipelined kernel
+    knobs(attn_two=two)  # 0: attn_kernel everywhere, 1: the two-query-block kernel from Lq >= 512
     C = 64 * H
     g = torch.Generator().manual_seed(31)
     q = torch.randn((B, Lq, H, 64), generator=g)
@@ -830,59 +803,6 @@ def test_conv_splitk_small_images(dev, n, ih, iw, cin, cout, stride):
     assert torch.equal(o3, o2[(n - 1) * oh * ow:])
 
 
-@pytest.mark.parametrize("kind,shape", [("gemm", (13608, 1280, 5120)), ("gemm", (54432, 640, 2560)), ("gemm", (13608, 1280, 1280)),
-                                        ("gemm", (70000, 256, 512)), ("conv", (42, 18, 18, 1280, 1280, 1)),
-                                        ("conv", (42, 36, 36, 640, 640, 1)), ("conv", (42, 36, 36, 640, 1280, 2)),
-                                        ("conv", (21, 40, 24, 128, 384, 1)), ("conv", (16, 72, 72, 64, 320, 1)),
-                                        ("conv", (16, 72, 72, 320, 320, 1))])
-def test_streamk_bitwise_equal_to_unsplit(dev, kind, shape, knobs):
-    """Stream-K (gemm_sk.hip: a tile that straddles two workgroups' ranges is CONTINUED from the exported accumulators) gives
-    bitwise the output and the epilogue statistics of the unsplit kernel on random data, with bias + row_add + residual; the
-    workspace flags are left zero, the error slot stays 0.  Two DIFFERENT data sets alternate through ONE workspace (a hand-off
-    that read stale or early data would go unnoticed if every launch wrote the same partial tiles)."""
-    from seva import ops
-    from seva._engine import pack_conv3x3
-    _need_exp_lib("the stream-K kernels")
-
-    def case(seed):
-        if kind == "gemm":
-            M, N, K = shape
-            a = _rand((M, K), dev, seed).half()
-            w = _rand((N, K), dev, seed + 1, 0.05).half()
-            rpg = 324
-            fn = lambda o, st, ws: ops.gemm(a, w, bias=bias, row_add=radd, rows_per_group=rpg, residual=res, out_f32=o, ch_stats=st,
-                                            splitk_ws=ws)
-        else:
-            n, ih, iw, cin, N, stride = shape
-            oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
-            M, rpg = n * oh * ow, oh * ow
-            x = _rand((n, ih, iw, cin), dev, seed).half()
-            w = pack_conv3x3(_rand((N, cin, 3, 3), dev, seed + 1, 0.05)).half()
-            fn = lambda o, st, ws: ops.conv3x3(x, w, stride=stride, bias=bias, row_add=radd, rows_per_group=rpg, residual=res,
-                                               out_f32=o, ch_stats=st, splitk_ws=ws)
-        bias, res = _rand((N,), dev, seed + 2), _rand((M, N), dev, seed + 3)
-        radd = _rand(((M + rpg - 1) // rpg, N), dev, seed + 4)
-        return fn, M, N
-
-    (fa, M, N), (fb, _, _) = case(1), case(101)
-    ws = ops.splitk_workspace(M, N, dev)
-    refs = []
-    knobs(gemm_streamk=0)
-    for fn in (fa, fb):
-        o_ref, st_ref = torch.empty((M, N), device=dev), torch.empty(ops.channel_stats_shape(M, N), device=dev)
-        fn(o_ref, st_ref, ws)
-        refs.append((o_ref, st_ref))
-    knobs(gemm_streamk=1)  # forced wherever eligible
-    for it in range(6):
-        fn, (o_ref, st_ref) = (fa, fb)[it & 1], refs[it & 1]
-        o = torch.full((M, N), float("nan"), device=dev)
-        st = torch.full_like(st_ref, float("nan"))
-        fn(o, st, ws)
-        assert torch.equal(o, o_ref), f"launch {it}: max diff {(o - o_ref).abs().max()}"
-        assert torch.equal(st, st_ref)
-        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
-
-
 @pytest.mark.parametrize("n,hw,c1,c2,dense", [(3, 256, 320, 0, True), (2, 1024, 128, 0, False), (2, 64, 640, 320, True),
                                               (5, 5184, 320, 320, False)])
 def test_groupnorm_with_producer_statistics(dev, n, hw, c1, c2, dense):
@@ -1092,15 +1012,11 @@ def test_value_dict_and_cond_assembly(dev):
 
 @pytest.mark.parametrize("M,C", [(300, 64), (1000, 128), (515, 256), (2049, 320), (128, 320), (77, 320)])
 @pytest.mark.parametrize("with_res", [True, False])
-@pytest.mark.parametrize("variant", [8, 4])
-def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res, variant, knobs):
+def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res, knobs):
     """seva_ff_fused_f16 (GEGLU -> FF2 in one kernel, hidden activations in registers) against (a) the two-kernel path it
     replaces -- same f16 rounding of the hidden tensor, so they agree to fp32 accumulation-order noise -- and (b) fp32 torch."""
     from seva import ops
     from seva._engine import interleave_geglu
-    if variant == 4:
-        _need_exp_lib("the 4-wave fused feed-forward kernel")
-    knobs(ff_variant=variant)  # 8 (default): two waves per row group; 4: one wave per row group, 512 registers
     g = torch.Generator().manual_seed(91)
     a = torch.randn(M, C, generator=g).half().to(dev)
     w1 = (torch.randn(8 * C, C, generator=g) * C ** -0.5).half().to(dev)
@@ -1121,21 +1037,20 @@ def test_ff_fused_vs_two_kernels_and_fp32(dev, M, C, with_res, variant, knobs):
     torch.cuda.synchronize()
     assert torch.isfinite(o32).all()
     e_two, e_ref = rel_l2(o32, two), rel_l2(o32, ref)
-    assert e_two < (1e-4 if variant == 8 else 1e-12), e_two  # 4-wave: bit-identical; 8-wave: bias-first accumulation, f16 ties
+    assert e_two < 1e-4, e_two  # bias-first accumulation, f16 ties
     assert e_ref < 1e-3, e_ref
     assert torch.equal(o16, o32.half())
     o16b = torch.full((M, C), float("nan"), device=dev, dtype=torch.float16)  # f16-only output (time-mix tail)
     ops.ff_fused(a, wi, bi, w2, b2, residual=res, out_f16=o16b)
     assert torch.equal(o16b, o16)
-    if variant == 8:
-        # LayerNorm folded into the prologue: vs LayerNorm kernel -> fused kernel (same math, different summation order)
-        x = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dev)
-        gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
-        a_ln = torch.empty((M, C), device=dev, dtype=torch.float16)
-        ops.layernorm(x, gm, bt, a_ln)
-        want = torch.empty((M, C), device=dev)
-        ops.ff_fused(a_ln, wi, bi, w2, b2, residual=res, out_f32=want)
-        got = torch.full((M, C), float("nan"), device=dev)
-        ops.ff_fused(None, wi, bi, w2, b2, residual=res, out_f32=got, ln_x=x, ln_gamma=gm, ln_beta=bt)
-        e_ln = rel_l2(got, want)
-        assert torch.isfinite(got).all() and e_ln < 2e-4, e_ln  # f16 roundings of the normalised row flip at ties only
+    # LayerNorm folded into the prologue: vs LayerNorm kernel -> fused kernel (same math, different summation order)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dev)
+    gm, bt = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    a_ln = torch.empty((M, C), device=dev, dtype=torch.float16)
+    ops.layernorm(x, gm, bt, a_ln)
+    want = torch.empty((M, C), device=dev)
+    ops.ff_fused(a_ln, wi, bi, w2, b2, residual=res, out_f32=want)
+    got = torch.full((M, C), float("nan"), device=dev)
+    ops.ff_fused(None, wi, bi, w2, b2, residual=res, out_f32=got, ln_x=x, ln_gamma=gm, ln_beta=bt)
+    e_ln = rel_l2(got, want)
+    assert torch.isfinite(got).all() and e_ln < 2e-4, e_ln  # f16 roundings of the normalised row flip at ties only

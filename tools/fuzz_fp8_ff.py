@@ -63,9 +63,7 @@ for case in range(cases):
     else:
         C = rng.choice([64, 128, 256, 320, 320])
         M = rng.choice([1, 31, 128, 129, 500, 1111, 4097])
-        variant = rng.choice([8, 8, 4])
         ops.set_knob("gemm_chunks", -1); ops.set_knob("gemm_bm", -1)
-        ops.set_knob("ff_variant", variant)
         a = torch.randn(M, C, generator=g).half().to(dev)
         w1 = (torch.randn(8 * C, C, generator=g) * C ** -0.5).half().to(dev)
         b1 = (0.3 * torch.randn(8 * C, generator=g)).to(dev)
@@ -79,15 +77,14 @@ for case in range(cases):
         ops.gemm(a, wi, bias=bi, out_f16=hid, geglu=True)
         two = torch.empty((M, C), device=dev)
         ops.gemm(hid, w2, bias=b2, residual=res, out_f32=two)
-        # 4-wave kernel: same operation order as the pair -> bit-identical.  8-wave kernel: the GEGLU bias is the accumulators'
-        # initial value (added first instead of last) -> equal up to fp32 rounding of that one add
+        # the GEGLU bias is the accumulators' initial value (added first instead of last): equal up to fp32 rounding of that one add
         rel = float((got - two).norm() / two.norm())
-        ok = torch.equal(got, two) if variant == 4 else rel < 1e-4
-        desc = f"ff C={C} M={M} variant={variant} res={res is not None} rel {rel:.2e}"
+        ok = rel < 1e-4
+        desc = f"ff C={C} M={M} res={res is not None} rel {rel:.2e}"
     if not ok:
         bad += 1
         print("MISMATCH", case, desc, flush=True)
-for k in ("gemm_chunks", "gemm_bm", "ff_variant"):
+for k in ("gemm_chunks", "gemm_bm"):
     ops.set_knob(k, -1)
 print(f"fuzz seed {seed}: {cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -30,6 +30,7 @@ args = ap.parse_args()
 variants = [int(v) for v in args.variants.split(",")]
 
 # (side, cin, cout, calls per step, statistics emitted)
+UP_SHAPES = [(36, 640, 640, 1), (18, 1280, 1280, 1), (9, 1280, 1280, 1)]  # source side, cin, cout, calls per step (fused nearest-2x upsample)
 SHAPES = [(72, 320, 320, 9, True), (72, 960, 320, 1, True), (72, 640, 320, 2, True),
           (36, 640, 640, 9, False), (36, 320, 640, 1, False), (36, 1920, 640, 1, False), (36, 1280, 640, 1, False), (36, 960, 640, 1, False),
           (18, 1280, 1280, 9, False), (18, 640, 1280, 1, False), (18, 2560, 1280, 2, False), (18, 1920, 1280, 1, False),
@@ -127,5 +128,34 @@ for side, cin, cout, calls, stats in SHAPES:
     line += " rel " + " ".join(f"{rel[v]:.1e}" for v in variants[1:])
     print(line, flush=True)
 print("   conv total per step (ms): " + "  ".join(f"v{v} {tot[v]:.2f}" for v in variants), flush=True)
+print("== fused nearest-2x upsample + conv3x3: source side cin cout | us per variant | TFLOP/s", flush=True)
+totu = {v: 0.0 for v in variants}
+for side, cin, cout, calls in UP_SHAPES:
+    n = 42
+    M = n * 4 * side * side
+    x = torch.randn(n, side, side, cin, device=dev, dtype=torch.float16)
+    w = (torch.randn(cout, 9 * cin, device=dev) * 0.02).half()
+    b = torch.randn(cout, device=dev)
+    out = torch.empty(n, 4 * side * side, cout, device=dev)
+    st = torch.empty(ops.channel_stats_shape(M, cout), device=dev) if (4 * side * side) % 64 == 0 else None
+    kw = dict(bias=b, out_f32=out, ch_stats=st, upsample=True)
+    outs = {}
+    for v in variants:
+        run(x, w, v, **kw)
+        torch.cuda.synchronize()
+        outs[v] = out.clone()
+    rel = {v: float((outs[v] - outs[variants[0]]).norm() / outs[variants[0]].norm()) for v in variants[1:]}
+    best = {v: 1e30 for v in variants}
+    for _ in range(args.rounds):
+        for v in variants:
+            best[v] = min(best[v], timeit(lambda: run(x, w, v, **kw), args.iters))
+    fl = 2.0 * M * cout * 9 * cin
+    line = f"{side:3d}->{2 * side:3d} {cin:5d} {cout:5d} |"
+    for v in variants:
+        line += f" v{v} {best[v]:8.1f} us {fl / best[v] / 1e6:7.1f} TF |"
+        totu[v] += best[v] * calls / 1e3
+    line += " rel " + " ".join(f"{rel[v]:.1e}" for v in variants[1:])
+    print(line, flush=True)
+print("   upsample conv total per step (ms): " + "  ".join(f"v{v} {totu[v]:.2f}" for v in variants), flush=True)
 ops.set_knob("conv_win", -1)
 sys.exit(1 if nbad else 0)
