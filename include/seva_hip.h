@@ -107,6 +107,10 @@ typedef struct seva_gemm_desc {
   const void* a2;
   int64_t lda2;
   int64_t K2;
+  /* accounting only (ABI 8; seva_prof_collect): reduction length of the REFERENCE-equivalent operator when the executed one is
+   * longer -- zero-padded input channels (the stem: 11 of 64), split-precision [hi | lo] operands (K doubled).  0 = K.  The
+   * profiler's FLOP count of the launch is 2 M N alg_K, so that a kernel class's achieved TFLOP/s is never credited with padding. */
+  int64_t alg_K;
 } seva_gemm_desc;
 int seva_gemm_f16(const seva_gemm_desc* d, seva_stream_t stream);
 /* BASELINE config 5 ("fp8 weights, CDNA4 fp8 MFMA"): the same operator with BOTH operands in OCP e4m3 (a: [M][lda]

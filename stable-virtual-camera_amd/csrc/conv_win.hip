@@ -29,6 +29,7 @@
 #include "gemm_common.h"
 
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -222,31 +223,45 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
       const char* const tb = lds_b + cur * B_BYTES;
       int toff = UP ? 0 : (t / 3) * g.Wp + (t % 3);
       asm volatile("" : "+s"(toff));  // opaque: the nine taps' fragment addresses are formed here, not hoisted out of the slab loop (45 registers)
-      half8_t af[2][MI], bf[2][NJ];
+      // fragment reads + MFMAs of the tap.  FIRST: every fragment read is ISSUED before the first MFMA (hipcc otherwise re-uses one
+      // register quad for the second k-step's window fragments and waits for each read right in front of the five MFMAs that need it:
+      // ~100 exposed cycles four times per tap); the MFMAs then start behind counted lgkmcnt waits as the fragments arrive in order.
+      // Measured (profiles/r04_kconvwin_frags_first.log): +1.5 ... 9 % on the 4-wave family (two independent workgroups per CU), -8 ... 10 %
+      // on the 8-wave family, whose waves would all burst their 18 reads right behind the shared barrier: it keeps hipcc's interleaving.
+      const auto compute_tap = [&](auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        half8_t af[2][MI], bf[2][NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        int j;
-        if constexpr (UP) {
-          const int ky = t / 3, kx = t % 3;  // compile-time after unrolling
-          j = (ky == 0 ? a_rm[i] : ky == 1 ? a_base[i] : a_rp[i]) + (kx == 0 ? a_xp[i] - 1 : kx == 1 ? 0 : a_xp[i]) + toff;
-        } else {
-          j = a_base[i] + toff;
+        for (int i = 0; i < MI; ++i) {
+          int j;
+          if constexpr (UP) {
+            const int ky = t / 3, kx = t % 3;  // compile-time after unrolling
+            j = (ky == 0 ? a_rm[i] : ky == 1 ? a_base[i] : a_rp[i]) + (kx == 0 ? a_xp[i] - 1 : kx == 1 ? 0 : a_xp[i]) + toff;
+          } else {
+            j = a_base[i] + toff;
+          }
+          const int addr = j * 128 + ((fg ^ ((j >> 1) & 7)) << 4);
+          af[0][i] = *(const half8_t*)(win + addr);
+          af[1][i] = *(const half8_t*)(win + (addr ^ 64));
         }
-        const int addr = j * 128 + ((fg ^ ((j >> 1) & 7)) << 4);
-        af[0][i] = *(const half8_t*)(win + addr);
-        af[1][i] = *(const half8_t*)(win + (addr ^ 64));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bf[s2][j] = *(const half8_t*)(tb + b_off[s2] + j * 2048);
+        if constexpr (FIRST) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+      };
+      if constexpr (NW == 4) {
+        compute_tap(std::true_type{});
+      } else {  // (giving the two wave groups of the 8-wave workgroup different orders under a wave-uniform branch spills 139+ registers)
+        compute_tap(std::false_type{});
       }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[s2][j] = *(const half8_t*)(tb + b_off[s2] + j * 2048);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
       if constexpr (!DBW) {
         if (t == 8 && more) {  // every wave has read the last tap's fragments: the window is free for the next slab
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -982,7 +982,8 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     SEVA_REQUIRE(d->lda >= d->K && d->lda % (8 * KU) == 0, "gemm: lda=%lld invalid", (long long)d->lda);
   }
   hipStream_t s = (hipStream_t)stream;
-  const double flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
+  SEVA_REQUIRE(d->alg_K >= 0 && d->alg_K <= d->K, "gemm: alg_K=%lld outside [0, K]", (long long)d->alg_K);
+  const double flops = 2.0 * (double)d->M * (double)d->N * (double)(d->alg_K > 0 ? d->alg_K : d->K);  // reference-equivalent FLOP (seva_hip.h)
   // algorithmic HBM bytes: A (conv: the NHWC image) and W read once, residual read once, each output written once
   const double a_elems = (d->mode == 1 ? (double)d->n * d->ih * d->iw * d->cin : (double)d->M * (double)d->K);
   const double a2_bytes = (d->mode == 1 && d->a2) ? 2.0 * (double)d->M * (double)d->K2 : 0.0;

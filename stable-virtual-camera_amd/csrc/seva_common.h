@@ -60,6 +60,11 @@ struct SevaProfScope {
 // hipcc (ROCm 7.2) forms packed fp32 math freely (vector types, the SLP vectoriser), so every value that comes out of a load /
 // LDS read / lane permute and may feed packed math goes through first_read(): one `v_mov_b32` in place (no extra register), which
 // the compiler cannot fold away and which is then the register's first reader.
+#ifdef SEVA_NO_FIRST_READ  // A/B builds only (make variant EXTRA=-DSEVA_NO_FIRST_READ): what the rule costs; never shipped (the ISA test fails)
+__device__ __forceinline__ float first_read(float v) { return v; }
+__device__ __forceinline__ f32x2 first_read(f32x2 v) { return v; }
+__device__ __forceinline__ f32x4 first_read(f32x4 v) { return v; }
+#else
 __device__ __forceinline__ float first_read(float v) {
   asm("v_mov_b32 %0, %0" : "+v"(v));
   return v;
@@ -76,6 +81,7 @@ __device__ __forceinline__ f32x4 first_read(f32x4 v) {
   asm("v_mov_b32 %0, %0" : "+v"(v[3]));
   return v;
 }
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

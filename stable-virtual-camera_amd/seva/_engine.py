@@ -423,7 +423,7 @@ class SevaEngine:
             res = None
         elif cin != cout:
             res = self._buf("skip32", (n * hw, cout), F32)
-            ops.gemm(xs16, W[pfx + ".skip.w"], bias=W[pfx + ".skip.b"], out_f32=res)
+            ops.gemm(xs16, W[pfx + ".skip.w"], bias=W[pfx + ".skip.b"], out_f32=res, alg_k=cin)  # ([hi | lo] doubles K, not the FLOP credit)
         else:
             assert x2 is None
             res = x1
@@ -726,7 +726,8 @@ class SevaEngine:
         ops.nchw_to_nhwc_f16(x, concat, x16, split=sp_stem)
         cur = self._buf("out:" + stem.prefix, (n, h * w, stem.cout), F32)
         st_stem = self._stats_buf("out:" + stem.prefix, n * h * w, h * w, stem.cout)
-        ops.conv3x3(x16, W[stem.prefix + ".w"], bias=W[stem.prefix + ".b"], out_f32=cur, ch_stats=st_stem)
+        ops.conv3x3(x16, W[stem.prefix + ".w"], bias=W[stem.prefix + ".b"], out_f32=cur, ch_stats=st_stem,
+                    alg_k=9 * cin)  # (profiling counts the reference's 11 input channels, not the padded / split 64)
         self._produced(cur, st_stem)
         ch, cw = h, w
         hs = [(cur, ch, cw)]
@@ -759,7 +760,7 @@ class SevaEngine:
         ops.groupnorm(cur, None, W["out.0.g"], W["out.0.b"], g16, self.gn_ws, eps=1e-5, silu=True,
                       stats1=self._gn_stats(cur, None)[0], split_out=sp_head)
         o_nhwc = self._buf("head", (n, ch * cw, p.out_channels), F32)
-        ops.conv3x3(g16.view(n, ch, cw, cf2), W["out.2.w"], bias=W["out.2.b"], out_f32=o_nhwc)
+        ops.conv3x3(g16.view(n, ch, cw, cf2), W["out.2.w"], bias=W["out.2.b"], out_f32=o_nhwc, alg_k=9 * cfin)
         if out is None:
             out = torch.empty((n, p.out_channels, ch, cw), dtype=F32, device=self.device)
         ops.nhwc_to_nchw_f32(o_nhwc, out)

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("w_exp", c_void_p), ("out_f8", c_void_p), ("ldo8", c_int64),
         ("ch_stats", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
         ("a2", c_void_p), ("lda2", c_int64), ("K2", c_int64),
+        ("alg_K", c_int64),
     ]
 
 

@@ -41,8 +41,10 @@ def gemm(
     out_f8: torch.Tensor | None = None,
     ch_stats: torch.Tensor | None = None,
     splitk_ws: torch.Tensor | None = None,
+    alg_k: int = 0,
 ) -> None:
     """out = a @ w.T (+bias +row_add[group] +residual); a:[M,K] f16, w:[N,K] f16 (seva_gemm_f16).
+    alg_k: accounting only -- the reference-equivalent reduction length when K is padded / split-precision (seva_gemm_desc.alg_K).
     splitk_ws (`splitk_workspace`): only convolutions use it (seva_gemm_desc.splitk_ws); accepted and ignored for plain GEMMs.
     ch_stats (`channel_stats_buffer`): receives per-64-row-block, per-channel sum / sum of squares of out_f32 (GroupNorm
     statistics emitted by the epilogue; `groupnorm(stats1=...)`).
@@ -59,6 +61,7 @@ def gemm(
     d.bias, d.row_add, d.residual = ptr(bias), ptr(row_add), ptr(residual)
     d.out_f32, d.out_f16 = ptr(out_f32), ptr(out_f16)
     d.M, d.N, d.K = M, N, K
+    d.alg_K = alg_k
     d.lda = a.stride(0)
     d.ldr = residual.stride(0) if residual is not None else 0
     d.ldo32 = out_f32.stride(0) if out_f32 is not None else 0
@@ -187,6 +190,7 @@ def conv3x3(
     ch_stats: torch.Tensor | None = None,
     splitk_ws: torch.Tensor | None = None,
     a2: torch.Tensor | None = None,
+    alg_k: int = 0,
 ) -> None:
     """3x3 pad-1 conv as implicit GEMM; x: [n, ih, iw, cin] f16 NHWC, w: [cout, 9*cin] f16.
     a2 ([M, K2] f16, K2 % 64 == 0): a second operand folded into the reduction behind the nine taps, w: [cout, 9*cin + K2]
@@ -210,6 +214,7 @@ def conv3x3(
         d.a2, d.lda2, d.K2 = a2.data_ptr(), a2.stride(0), a2.shape[1]
         d.K = 9 * cin + a2.shape[1]
     assert w.shape[1] == d.K
+    d.alg_K = alg_k
     d.lda = cin
     d.ldr = residual.stride(-2) if residual is not None else 0
     d.ldo32 = out_f32.stride(-2) if out_f32 is not None else 0

@@ -84,7 +84,7 @@ def _epilogue(acc, M, N, bias, row_add, rows_per_group, ld_row_add, residual, ou
 
 def gemm(a, w, *, bias=None, row_add=None, rows_per_group=0, ld_row_add=0, residual=None,
          out_f32=None, out_f16=None, geglu=False, col_scale=1.0, col_scale_n=0, w_exp=None, out_f8=None, ch_stats=None,
-         splitk_ws=None):
+         splitk_ws=None, alg_k=0):
     M, N = a.shape[0], w.shape[0]
     if w_exp is not None:  # seva_gemm_fp8
         assert a.dtype == U8 and w.dtype == U8 and a.shape[1] % 128 == 0 and N % 16 == 0
@@ -124,7 +124,7 @@ def ff_fused(a, w1, b1, w2, b2, *, residual=None, out_f32=None, out_f16=None, ln
 
 def conv3x3(x, w, *, stride=1, upsample=False, bias=None, row_add=None, rows_per_group=0,
             ld_row_add=0, residual=None, out_f32=None, out_f16=None, pad_br_only=False, w_exp=None, ch_stats=None,
-            splitk_ws=None, a2=None):
+            splitk_ws=None, a2=None, alg_k=0):
     n, ih, iw, cin = x.shape
     w2 = None
     if a2 is not None:  # folded second operand (seva_gemm_desc.a2): the columns behind the nine taps multiply a2
