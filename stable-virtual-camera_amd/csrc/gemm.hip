@@ -107,6 +107,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   constexpr int NSC = (NJ + 3) / 4;  // packed scale words per lane
   // instantiations that can emit GroupNorm statistics (GemmArgs::ch_stats): a wave owns a 64-row block of the f32 output
   constexpr bool STATS_OK = EPI == 0 && !PAIRED && !ASTAT && !DBGK && WM == 64 && NJ >= 4;
+  // order of the fragment reads (see ktile): measured per kernel family, same box (profiles/r04_ab_gemm_frags_first.log): the f16-only /
+  // GEGLU kernels gain 2 - 5 % (36x36 GEGLU 419 -> 399 us), the fp32-output 160 x 160 kernels LOSE 5 % with the half measure their registers allow
+  constexpr int FRAGS_FIRST = (DBGK || FP8 || ASTAT || !PAIRED) ? 0 : BN == 160 ? 1 : 2;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [A buf0][A buf1][B buf0][B buf1]
@@ -480,6 +483,10 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
           for (int i = 0; i < MI; ++i) af[s][i] = *(const half8_t*)(ta + a_off[s] + i * (16 * 128));
 #pragma unroll
           for (int j = 0; j < NJ; ++j) bf[s][j] = *(const half8_t*)(tb + b_frag_off(s, j));
+          // FRAGS_FIRST (conv_win.hip measured what hipcc's own order costs: it re-uses a register quad for late fragments and waits for each
+          // read right in front of the MFMAs that need it): 2 = every fragment read of the K-tile is ISSUED before its first MFMA; 1 = the
+          // first k-step's reads are (the tiles that have no registers for both: 20 - 70 dwords of spill otherwise); 0 = hipcc's order
+          if (FRAGS_FIRST == 2 ? s == 1 : FRAGS_FIRST == 1 ? s == 0 : false) __builtin_amdgcn_sched_barrier(0);  // (folds after unrolling)
         }
       } else {
 #pragma unroll
