@@ -230,6 +230,13 @@ def trajectory_leg(net, device, rank, world, n, hw, T, steps, cfg_split):
         "window_times_ceiling": (0.5 if (cfg_split and world > 1) else 1.0) * len(plan.pass1)
                                 + sum(0.5 if len(r[0][1]) == 2 else 1.0 for r in sched),
         "handoff": "anchor latents (no decode/encode round trip); VAE decode of the frames not included",
+        # which definition a speed-up over one GPU refers to: WHOLE trajectory wall time, serial first pass included.
+        # One GPU = (windows of pass 1 + pass 2) window-times; N GPUs = window_times_ceiling.  For the 168-view plan (1 + 10 windows) on
+        # 8 GPUs that is 11 / 2.0 = 5.5x with CFG-split (3.7x without): north_star's >= 6x is NOT reachable by sharding whole windows and
+        # the two CFG halves -- it needs intra-window sharding (heads / query blocks of the joint attention over more than two ranks)
+        "speedup_definition": "whole-trajectory wall time vs one GPU (pass 1 + pass 2); ideal = (n_pass1 + n_pass2) / window_times_ceiling",
+        "ideal_speedup_vs_one_gpu": (len(plan.pass1) + len(plan.pass2)) / ((0.5 if (cfg_split and world > 1) else 1.0) * len(plan.pass1)
+                                                                       + sum(0.5 if len(r[0][1]) == 2 else 1.0 for r in sched)),
     }
 
 

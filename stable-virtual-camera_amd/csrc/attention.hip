@@ -549,6 +549,26 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
     // ---- S^T = K Q^T for both query blocks off ONE K fragment; accumulators start at -m_run (q carries scale*log2e) ----
     f32x16 sc[QB][KB];
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (!SPLIT) {
+      // every K fragment of the tile is ISSUED before the first score MFMA (hipcc otherwise reads one pair ahead and waits for it in front
+      // of every two MFMAs).  Measured, same box (profiles/r04_kattn_frags_first.log): per-frame attention at 72x72 1834 -> 1788 us; the K/V-split
+      // instantiation spills 7 registers with it and keeps hipcc's order; the same for the V^T fragments of the P V phase loses 1 - 3 %
+      half8_t kfa[KB][4];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int krow = 32 * kb + qi;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kfa[kb][s] = *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int c = 0; c < QB; ++c)
+            sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfa[kb][s], qf[c][s], s == 0 ? neg_m[c] : sc[c][kb], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int krow = 32 * kb + qi;
@@ -564,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
           }
         }
       }
+    }
     }
     __builtin_amdgcn_s_setprio(0);
     // ---- online softmax per query block: mask, running maximum, rare rescale; exp2 / pack / row sums ----

@@ -25,7 +25,11 @@ for case in range(ncases):
     kn = {}
     if mode == "s2br" and (ih % 2 or iw % 2):
         mode = "s2"
-    for k, vals in (("SEVA_GEMM_BN", [None, "128", "160"]), ("SEVA_GEMM_BM", [None, None, "64", "128", "160"]), ("SEVA_GEMM_CHUNKS", [None, "1", "2"])):
+    # (the tile knobs switch the window-staged kernel off: half of the cases leave them all unset and pick one of its families instead)
+    tile_knobs = rng.random() < 0.5
+    ops.set_knob("conv_win", -1 if tile_knobs else rng.choice([-1, 1, 2]))
+    for k, vals in (("SEVA_GEMM_BN", [None, "128", "160"] if tile_knobs else [None]), ("SEVA_GEMM_BM", [None, None, "64", "128", "160"] if tile_knobs else [None]),
+                    ("SEVA_GEMM_CHUNKS", [None, "1", "2"] if tile_knobs else [None])):
         v = rng.choice(vals)
         kn[k] = v
         ops.set_knob(k[5:].lower(), -1 if v is None else int(v))  # knobs are read from the environment only at load
@@ -69,5 +73,6 @@ for case in range(ncases):
     if not ok:
         bad += 1
         print("MISMATCH", case, n, ih, iw, cin, cout, mode, stats is not None, use_sk, {k: os.environ.get(k) for k in ("SEVA_GEMM_BN", "SEVA_GEMM_BM", "SEVA_GEMM_CHUNKS")}, flush=True)
+ops.set_knob("conv_win", -1)
 print(f"conv fuzz: {ncases} cases, {bad} mismatches; with statistics {cnt['stats']}, split-K candidates {cnt['splitk']}")
 sys.exit(1 if bad else 0)

@@ -2,7 +2,7 @@
 # One eager (no hipGraph) bench step under rocprofv3: kernel-trace stats + two PMC passes (FETCH_SIZE, WRITE_SIZE).
 # Run on the GPU box from the repo root; results land in gpurun_out/prof_<tag>/.
 set -e
-tag=${1:-r02}
+tag=${1:-r04}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp SEVA_HIPGRAPH=0

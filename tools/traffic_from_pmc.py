@@ -17,8 +17,9 @@ import sys
 import re
 
 # kernel names: gemm_kernel<BM, BN, MODE, EPI, DBG> (MODE 0 plain / 1 conv3x3), attn_kernel<NW, KT, ...>
-CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128|160), (128|160), 0, |gemm_sk_kernel<\d+, 0>|ff_fused"), "conv": re.compile(r"gemm_kernel<(64|128|160), (128|160), [12], |gemm_sk_kernel<\d+, [12]>"),
-           "attention": re.compile(r"attn_kernel<4, 64|attn2_kernel|attn3_kernel")}
+CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128|160), (128|160), 0, |ff_fused"),
+           "conv": re.compile(r"gemm_kernel<(64|128|160), (128|160), [123], |conv_win_kernel"),
+           "attention": re.compile(r"attn_kernel<4, 64|attn2_kernel")}
 
 
 def load(d, counter):
@@ -45,7 +46,7 @@ if __name__ == "__main__":
             read_b, write_b = 2.0 * rd[cls][0], wr[cls][0]
             res[cls] = {"bytes_per_launch": (read_b + write_b) / n, "launches": n,
                         "read_bytes": read_b, "write_bytes": write_b,
-                        "note": "FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE, summed over all launches of the class in one eager step"}
+                        "note": "FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE, summed over all launches of the class in the profiled run (every eager step of it, warm-up included); bytes_per_launch is the figure to read"}
     import subprocess
     try:
         res["git"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("SEVA_GIT_REV")
