@@ -759,6 +759,390 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong variant of attn2_kernel: ONE 8-wave workgroup per CU (512 queries per K/V tile), the two waves of a SIMD
+// (waves w and w + 4) held one segment apart by workgroup barriers, so that one of them is in its MFMA segment
+//   M_t = { O^T += V^T(t-1) P^T(t-1) ; S^T(t) = K(t) Q^T for both query blocks }      (32 MFMAs, LDS fragment reads, the tile's DMA issue)
+// while its partner is in its VALU segment
+//   V_t = { exp2 / pack / row sums of tile t (rare: maximum + rescale) }               (~150 VALU instructions, no MFMA, no memory)
+// and the next barrier swaps the roles.  Two independent 4-wave workgroups per CU (attn2_kernel) drift into the same phase -- both
+// waves of a SIMD in their MFMAs, then both in their softmax: the MFMA pipe is 47 % busy there -- and nothing but a barrier shared by
+// the two partners can hold them apart (MI355X guide, "Two waves per SIMD").  Per wave the instruction ORDER is attn2_kernel's with the
+// P V product of tile t moved behind the scores of tile t + 1: the same MFMAs on the same operands in the same accumulation order, the
+// same rescale points -> bitwise equal results (tests/test_ops_gpu.py).  No extra registers: sc lives M -> V, pf lives V -> M.
+// K/V ring of four 16 KB tiles: in segment pair (2t, 2t + 1) the groups read K(t) and V(t - 1), tile t + 1 has landed, tile t + 2 is
+// issued into the buffer of tile t - 2 (one K and one V piece per wave; each wave waits for its own pieces of tile t + 1 at the end of
+// its M_t, two barriers before anyone reads them).
+template <int KT, bool SPLIT = false>
+__global__ __launch_bounds__(512, 1) void attn4_kernel(AttnArgs p) {
+  constexpr int NW = 8, QB = 2, KB = KT / 32, NBUF = 4;
+  constexpr int BUF_BYTES = 2 * KT * 128;
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
+  static_assert(KT / 8 / NW == 1, "one K and one V piece per wave and tile");
+  constexpr int G = 2;
+  static_assert(NBUF * BUF_BYTES >= NW * QB * 32 * 128, "the output staging re-uses the ring");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int qi = lane & 31, hh = lane >> 5;
+
+  int bid;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7;
+    bid = ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+  }
+  const int qb = bid % p.qblocks;
+  bid /= p.qblocks;
+  int ksp = 0;
+  if (SPLIT) {
+    ksp = bid % p.nsplit;
+    bid /= p.nsplit;
+  }
+  const int head = bid % p.heads;
+  const int batch = bid / p.heads;
+  const int b0 = batch / p.nb1, b1 = batch - b0 * p.nb1;
+  int key0 = 0, lk = p.lk;
+  if (SPLIT) {
+    const int nt_all = (p.lk + KT - 1) / KT, tps = (nt_all + p.nsplit - 1) / p.nsplit;
+    key0 = ksp * tps * KT;
+    const int key1 = (ksp + 1) * tps * KT < p.lk ? (ksp + 1) * tps * KT : p.lk;
+    lk = key1 - key0;
+  }
+
+  const half_t* const qbase = p.q + b0 * p.q_sb0 + b1 * p.q_sb1 + head * 64;
+  const half_t* const kbase = p.k + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64 + (int64_t)key0 * p.k_sl;
+  const half_t* const vbase = p.v + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64 + (int64_t)key0 * p.k_sl;
+  half_t* const obase = p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64;
+
+  half8_t qf[QB][4];
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    const int qrow = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c + qi;
+    const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[c][s] = *(const half8_t*)(qbase + (int64_t)qrow_c * p.q_sl + 16 * s + 8 * hh);
+  }
+  // a wave whose 64 query rows all lie past lq keeps feeding the ring and meeting the barriers but computes nothing
+  const bool active = __builtin_amdgcn_readfirstlane(qb * (32 * QB * NW) + wave * (32 * QB)) < p.lq;
+  f32x16 acc_o[QB][2];
+  float m_run[QB], l_run[QB];
+  f32x16 neg_m[QB];
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    m_run[c] = 0.f;
+    l_run[c] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) neg_m[c][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[c][d][r] = 0.f;
+  }
+  constexpr float P_SUM_BOUND = 16384.0f;
+
+  const int nt = (lk + KT - 1) / KT;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int group = wave_u >> 2;  // SIMD partners are waves w and w + 4: group 1 runs one segment behind group 0
+  const unsigned smem_base =
+      __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int sr = lane >> 3, sp = lane & 7;
+  const half_t* kp;
+  const half_t* vp;
+  {
+    const int row = 8 * wave_u + sr;
+    const int key = row < lk ? row : lk - 1;
+    kp = kbase + (int64_t)key * p.k_sl + k_chunk_swz(row, sp) * 8;
+    vp = vbase + (int64_t)key * p.k_sl + v_chunk_swz(row, sp) * 8;
+  }
+  const int64_t tile_stride = (int64_t)KT * p.k_sl;
+  const bool ragged = (lk % KT) != 0;
+  auto issue_tile = [&](int kt) {  // tiles are issued strictly in order 0, 1, 2, ... into buffer kt % NBUF
+    const unsigned dst = smem_base + (kt & (NBUF - 1)) * BUF_BYTES + 8 * wave_u * 128;
+    if (ragged && kt == nt - 1 && kt > 0) {
+      const int row = 8 * wave_u + sr;
+      int key = kt * KT + row;
+      if (key >= lk) key = lk - 1;
+      const int64_t roff = (int64_t)key * p.k_sl;
+      glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
+      glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
+    } else {
+      glds16_raw(kp, dst);
+      glds16_raw(vp, dst + KT * 128);
+    }
+    kp += tile_stride;
+    vp += tile_stride;
+  };
+  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+  typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+  const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
+
+  f32x16 sc[QB][KB];       // scores of the tile in flight: written by M_t, consumed by V_t
+  half8_t pf[QB][KB][2];   // its probabilities: written by V_t, consumed by M_(t+1)
+
+  // Fragments are read one segment AHEAD (at the end of the wave's V segment, into the registers the dead scores leave free), so an M
+  // segment is MFMAs only: read right before use they exposed the LDS latency in front of every MFMA pair (M = 1530 - 1780 cycles for
+  // 1024 of MFMA, tools/kattn_stamps.py) -- two independent workgroups cover that for each other, SIMD partners in opposite roles cannot.
+  half8_t kf[KB][4];      // K(t) fragments for the scores of M_t
+  half8_t vf[2][KB][2];   // V^T(t-1) fragments for the P V product of M_t
+  auto read_k = [&](int kt) {
+    const char* const lds_k = smem + (kt & (NBUF - 1)) * BUF_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int krow = 32 * kb + qi;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[kb][s] = *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
+    }
+  };
+  auto read_v = [&](int kt) {
+    const char* const lds_v = smem + (kt & (NBUF - 1)) * BUF_BYTES + KT * 128;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int r0 = 32 * kb + 16 * s2 + 4 * hh;
+          const int colbyte = (32 * db + 16 * (g16 & 1) + 4 * p4) * 2;
+          const int ch = colbyte >> 4, within = colbyte & 15;
+          const int ra = r0 + q4, rb = r0 + 8 + q4;
+          vf[db][kb][s2] = tr_read_pair(lds_v + ra * 128 + (v_chunk_swz(ra, ch) << 4) + within,
+                                        lds_v + rb * 128 + (v_chunk_swz(rb, ch) << 4) + within);
+        }
+  };
+  auto scores = [&]() {  // S^T(t) = K(t) Q^T, accumulators start at -m_run
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < QB; ++c) sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][s], qf[c][s], s == 0 ? neg_m[c] : sc[c][kb], 0, 0, 0);
+  };
+  auto pv = [&]() {  // O^T += V^T(t-1) P^T(t-1)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int c = 0; c < QB; ++c)
+            acc_o[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db][kb][s2], pf[c][kb][s2], acc_o[c][db], 0, 0, 0);
+  };
+  auto softmax = [&](int kt, auto masked_c) {  // attn2_kernel's, statement for statement
+    constexpr bool MASKED = decltype(masked_c)::value;
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+      if (MASKED) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= lk) sc[c][kb][r] = -1e30f;
+          }
+      }
+      float ls[4];
+      const auto exp_pack = [&]() {
+        ls[0] = ls[1] = ls[2] = ls[3] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            fp16x2_t pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float e0 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j]);
+              const float e1 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j + 1]);
+              pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+              ls[j] = __builtin_amdgcn_fdot2(pk[j], ones2, ls[j], false);
+            }
+            pf[c][kb][s2] = __builtin_bit_cast(half8_t, pk);
+          }
+        return (ls[0] + ls[1]) + (ls[2] + ls[3]);
+      };
+      float tot = exp_pack();
+      const bool first = kt == 0;
+      if (__builtin_expect(first || __any(!(tot < P_SUM_BOUND)), 0)) {
+        float mk[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          mk[kb] = sc[c][kb][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mk[kb] = fmaxf(mk[kb], sc[c][kb][r]);
+        }
+        float mx = mk[0];
+#pragma unroll
+        for (int kb = 1; kb < KB; ++kb) mx = fmaxf(mx, mk[kb]);
+        mx = half_wave_max(mx);
+        const float delta = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        m_run[c] += delta;
+        l_run[c] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) neg_m[c][r] = -m_run[c];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc_o[c][d][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[c][kb][r] -= delta;
+        tot = exp_pack();
+      }
+      l_run[c] += tot;
+    }
+  };
+  const auto barrier = [&]() {  // a segment boundary: nothing moves across it, neither memory operations nor arithmetic
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  issue_tile(0);
+  if (nt > 1) issue_tile(1);
+  wait_vm<0>();
+#pragma unroll
+  for (int c = 0; c < QB; ++c)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[c][s]));  // retire the Q loads (see attn_kernel)
+  barrier();
+  if (group == 1) barrier();  // the skew: from here on group 1 is one segment behind
+  const int nfull = lk / KT;
+  // V segments run at priority 1: the younger half of the workgroup (waves 4 - 7) otherwise loses the VALU arbitration against its
+  // partner's MFMA stream (V = 1900 cycles against 1080 for the older half); an MFMA needs one issue slot in 32 cycles
+#ifndef SEVA_ATTN4_PRIO
+#define SEVA_ATTN4_PRIO 1
+#endif
+  const auto end_v = [&](int kt) {  // the next M segment's fragments; own DMA pieces (tile kt + 2, issued two segments ago) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    read_v(kt);
+    if (kt + 1 < nt) read_k(kt + 1);
+    if (SEVA_ATTN4_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    wait_vm<0>();
+    barrier();
+    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+  };
+  const auto end_m = [&]() {
+    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    barrier();
+    if (SEVA_ATTN4_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+  };
+  if (active) {
+    // sc, pf, kf, vf are written UNCONDITIONALLY in every segment that writes them (a conditional write keeps the old value alive, and
+    // the blocks together do not fit the register file): the idle waves have their own loop
+    read_k(0);
+    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    for (int kt = 0; kt < nfull; ++kt) {
+#ifdef SEVA_ATTN_STAMP  // diagnostic build only (tools/kattn_stamps.py): s_memtime at the segment boundaries of tiles 8..15 of workgroup 0
+      const bool stamp = !SPLIT && p.part_o != nullptr && blockIdx.x == 0 && kt >= 8 && kt < 16 && lane == 0;
+      unsigned long long* const st = (unsigned long long*)p.part_o + (wave_u * 8 + (kt - 8)) * 8;
+      if (stamp) st[0] = __builtin_amdgcn_s_memtime();
+#endif
+      if (kt + 2 < nt) issue_tile(kt + 2);
+      if (kt > 0) pv();  // first: pf dies here, before sc is written
+      scores();
+#ifdef SEVA_ATTN_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      if (stamp) st[1] = __builtin_amdgcn_s_memtime();  // the last MFMA has ISSUED (in order, 32 cycles apart)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      end_m();
+#ifdef SEVA_ATTN_STAMP
+      if (stamp) st[2] = __builtin_amdgcn_s_memtime();
+#endif
+      softmax(kt, std::false_type{});
+#ifdef SEVA_ATTN_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      if (stamp) st[3] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      end_v(kt);
+#ifdef SEVA_ATTN_STAMP
+      if (stamp) st[4] = __builtin_amdgcn_s_memtime();
+#endif
+    }
+    if (nfull < nt) {  // the ragged last tile
+      if (nfull > 0) pv();
+      scores();
+      end_m();
+      softmax(nfull, std::true_type{});
+      end_v(nfull);
+    }
+    pv();
+    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+  } else {
+    for (int kt = 0; kt < nt; ++kt) {
+      if (kt + 2 < nt) issue_tile(kt + 2);
+      barrier();
+      wait_vm<0>();
+      barrier();
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (group == 0) barrier();
+  barrier();  // every wave is done reading K/V tiles
+
+  if constexpr (SPLIT) {
+    const int64_t rows_all = (int64_t)gridDim.x / (p.qblocks * p.nsplit) * p.lq;  // batch * heads * lq
+    const int64_t row_bh = ((int64_t)batch * p.heads + head) * p.lq;
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+      const int qrow = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c + qi;
+      const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
+      if (qrow < p.lq) {
+        float* const po = p.part_o + ((int64_t)ksp * rows_all + row_bh + qrow) * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            *(f32x4*)(po + 32 * db + 8 * t + 4 * hh) =
+                f32x4{acc_o[c][db][4 * t], acc_o[c][db][4 * t + 1], acc_o[c][db][4 * t + 2], acc_o[c][db][4 * t + 3]};
+        if (hh == 0) {
+          float* const pm = p.part_ml + ((int64_t)ksp * rows_all + row_bh + qrow) * 2;
+          pm[0] = m_run[c];
+          pm[1] = l_tot;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
+    const float inv = 1.0f / l_tot;
+    char* const ow = smem + (wave * QB + c) * (32 * 128);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        half4_t h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[c][db][4 * t + r] * inv);
+        const int d0 = 32 * db + 8 * t + 4 * hh;
+        const int chunk = d0 >> 3, piece = (d0 >> 2) & 1;
+        *(half4_t*)(ow + qi * 128 + ((chunk ^ (qi & 7)) << 4) + (piece << 3)) = h;
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < QB; ++c) {
+    const char* const ow = smem + (wave * QB + c) * (32 * 128);
+    const int q0 = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (lane >> 3), pchunk = lane & 7;
+      const uint4 v = *(const uint4*)(ow + row * 128 + (pchunk << 4));
+      const int lchunk = pchunk ^ (row & 7);
+      if (q0 + row < p.lq) *(uint4*)(obase + (int64_t)(q0 + row) * p.o_sl + lchunk * 8) = v;
+    }
+  }
+}
+
 // Combine of the K/V-split partials: out = sum_i 2^(m_i - m*) O_i / sum_i 2^(m_i - m*) l_i, one thread per (row, 8 columns).
 // Fixed order over the splits, exp2 of exact differences: deterministic, and (the split being a function of the sequence
 // lengths only) independent of what else is in the batch.
@@ -859,9 +1243,12 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   // (+3.6 ... +6.2 % at the three long shapes of a step, -1 % at L = 1296).  Knob attn_two: 0 forces attn_kernel, 1 selects this
   // kernel from lq >= 512, 3 the software-pipelined kernel above (experimental library only).
   const int two = g_seva_knobs.attn_two;
-  if (pre && use_tr && !a.dbg && ((two < 0 && d->lq >= 2048) || ((two == 1 || two == 2) && d->lq >= 512))) {
+  if (pre && use_tr && !a.dbg && ((two < 0 && d->lq >= 2048) || ((two == 1 || two == 2 || two == 4) && d->lq >= 512))) {
+    // knob attn_two = 4: the ping-pong kernel (one 8-wave workgroup per CU, 512 queries per K/V tile)
+    const bool pp = two == 4;
+    const int qrows = pp ? 512 : 256;
     AttnArgs args = a;
-    args.qblocks = (a.lq + 255) / 256;
+    args.qblocks = (a.lq + qrows - 1) / qrows;
     const int64_t nb = batch * a.heads * args.qblocks;
     if (nb <= 0 || nb > 0x7fffffff) {
       seva_set_error("attention: bad grid %lld", (long long)nb);
@@ -882,13 +1269,18 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
       args.nsplit = nsplit;
       args.part_o = d->split_ws;
       args.part_ml = d->split_ws + (int64_t)nsplit * rows_all * 64;
-      hipLaunchKernelGGL((attn2_kernel<64, true>), dim3((unsigned)(nb * nsplit)), dim3(256), 0, s, args);
+      if (pp) hipLaunchKernelGGL((attn4_kernel<64, true>), dim3((unsigned)(nb * nsplit)), dim3(512), 0, s, args);
+      else hipLaunchKernelGGL((attn2_kernel<64, true>), dim3((unsigned)(nb * nsplit)), dim3(256), 0, s, args);
       int rc = seva_check_launch("attn2_kernel<split>");
       if (rc) return rc;
       hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((rows_all * 8 + 255) / 256)), dim3(256), 0, s, args, rows_all);
       return seva_check_launch("attn_combine_kernel");
     }
-    hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
+#ifdef SEVA_ATTN_STAMP
+    args.part_o = d->split_ws;  // stamps of workgroup 0 (8 waves x 8 tiles x 8 words of 8 bytes)
+#endif
+    if (pp) hipLaunchKernelGGL((attn4_kernel<64>), dim3((unsigned)nb), dim3(512), 0, s, args);
+    else hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
     return seva_check_launch("attn2_kernel");
   }
   return launch<4, 64>(a, batch, s, use_tr, pre);

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Ping-pong attention (attn4_kernel, knob attn_two = 4: one 8-wave workgroup per CU, SIMD partners one segment apart) against the
+production kernel (attn2_kernel: two independent 4-wave workgroups per CU) on the long attention shapes of a step:
+
+    python tools/kattn_pp.py [--iters N] [--rounds R]
+
+1. bit-equality of the two kernels (same MFMAs, same accumulation order, same rescale points), also on ragged / short / split cases;
+2. interleaved timing."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
+import torch  # noqa: E402
+
+from seva import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--splits", default="-1")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+LOG2E = 1.4426950408889634
+
+
+def make(B, H, L, seed=0, spike=False):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    C = 64 * H
+    qkv = torch.randn(B * L, 3 * C, device=dev, generator=g)
+    if spike:  # a few keys far above the rest: the rescale path
+        qkv[::997, C:2 * C] *= 6.0
+    qkv[:, :C] *= 0.125 * LOG2E
+    return qkv.half(), C
+
+
+def run(qkv, C, B, H, L, knob, ws, split):
+    ops.set_knob("attn_two", knob)
+    ops.set_knob("attn_split", split)
+    o = torch.full((B * L, C), float("nan"), device=dev, dtype=torch.float16)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, nb0=B, nb1=1, heads=H, lq=L, lk=L, q_strides=(L * 3 * C, 0, 3 * C),
+                  k_strides=(L * 3 * C, 0, 3 * C), o_strides=(L * C, 0, C), q_prescaled=True, split_ws=ws)
+    torch.cuda.synchronize()
+    return o
+
+
+nbad = 0
+for B, H, L, split, spike in [(3, 2, 512, 0, False), (2, 3, 577, 0, True), (1, 2, 1100, 0, False), (2, 2, 2048 + 65, 2, True), (1, 1, 4096, 3, False),
+                              (1, 2, 6804, -1, True), (5, 5, 5184, 0, False), (2, 1, 640, 4, False), (1, 1, 513, 0, False), (1, 1, 700, 0, True)]:
+    qkv, C = make(B, H, L, seed=L, spike=spike)
+    ws = torch.empty(ops.attention_split_workspace_numel(B, H, L, 4), device=dev)
+    a = run(qkv, C, B, H, L, 2, ws, split)
+    b = run(qkv, C, B, H, L, 4, ws, split)
+    ok = torch.equal(a, b) and bool(torch.isfinite(b.float()).all())
+    nbad += not ok
+    print(f"bitwise B={B} H={H} L={L} split={split} spike={spike}: {'OK' if ok else 'MISMATCH max ' + str(float((a.float() - b.float()).abs().nan_to_num(1e9).max()))}", flush=True)
+print(f"bit-equality: {nbad} mismatches", flush=True)
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+print("== shape | split | us attn2 (TFLOP/s) | us attn4 ping-pong (TFLOP/s)", flush=True)
+for name, B, H, L, calls in [("ds1 frame", 42, 5, 5184, 5), ("ds2 joint", 2, 10, 27216, 3), ("ds4 joint", 2, 20, 6804, 3), ("ds2 frame", 42, 10, 1296, 2),
+                             ("clean 4096", 8, 8, 4096, 0), ("clean 8192", 4, 8, 8192, 0)]:
+    qkv, C = make(B, H, L)
+    ws = torch.empty(ops.attention_split_workspace_numel(B, H, L, 4), device=dev)
+    o = torch.empty(B * L, C, device=dev, dtype=torch.float16)
+    fl = 4.0 * B * H * L * L * 64
+
+    def call(knob, split):
+        ops.set_knob("attn_two", knob)
+        ops.set_knob("attn_split", split)
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, nb0=B, nb1=1, heads=H, lq=L, lk=L, q_strides=(L * 3 * C, 0, 3 * C),
+                      k_strides=(L * 3 * C, 0, 3 * C), o_strides=(L * C, 0, C), q_prescaled=True, split_ws=ws)
+
+    for split in [int(x) for x in args.splits.split(",")]:
+        best = {2: 1e30, 4: 1e30}
+        for _ in range(args.rounds):
+            for knob in (2, 4):
+                best[knob] = min(best[knob], timeit(lambda: call(knob, split), args.iters))
+        print(f"{name:10s} B={B:3d} H={H:2d} L={L:6d} | split {split:2d} | {best[2]:8.1f} ({fl / best[2] / 1e6:6.1f}) | {best[4]:8.1f} ({fl / best[4] / 1e6:6.1f})", flush=True)
+ops.set_knob("attn_two", -1)
+ops.set_knob("attn_split", -1)
+sys.exit(1 if nbad else 0)
