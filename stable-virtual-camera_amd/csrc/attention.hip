@@ -760,32 +760,34 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ping-pong variant of attn2_kernel: ONE 8-wave workgroup per CU (512 queries per K/V tile), the two waves of a SIMD
-// (waves w and w + 4) held one segment apart by workgroup barriers, so that one of them is in its MFMA segment
-//   M_t = { O^T += V^T(t-1) P^T(t-1) ; S^T(t) = K(t) Q^T for both query blocks }      (32 MFMAs, LDS fragment reads, the tile's DMA issue)
-// while its partner is in its VALU segment
-//   V_t = { exp2 / pack / row sums of tile t (rare: maximum + rescale) }               (~150 VALU instructions, no MFMA, no memory)
-// and the next barrier swaps the roles.  Two independent 4-wave workgroups per CU (attn2_kernel) drift into the same phase -- both
-// waves of a SIMD in their MFMAs, then both in their softmax: the MFMA pipe is 47 % busy there -- and nothing but a barrier shared by
-// the two partners can hold them apart (MI355X guide, "Two waves per SIMD").  Per wave the instruction ORDER is attn2_kernel's with the
-// P V product of tile t moved behind the scores of tile t + 1: the same MFMAs on the same operands in the same accumulation order, the
-// same rescale points -> bitwise equal results (tests/test_ops_gpu.py).  No extra registers: sc lives M -> V, pf lives V -> M.
-// K/V ring of four 16 KB tiles: in segment pair (2t, 2t + 1) the groups read K(t) and V(t - 1), tile t + 1 has landed, tile t + 2 is
-// issued into the buffer of tile t - 2 (one K and one V piece per wave; each wave waits for its own pieces of tile t + 1 at the end of
-// its M_t, two barriers before anyone reads them).
+// attn2_kernel's two-block scheme on v_mfma_f32_16x16x32_f16: a wave owns 64 query rows as FOUR 16-row blocks and every K fragment
+// and V^T fragment it reads from LDS feeds all four blocks' MFMAs.  Why the other MFMA shape: the chip holds its clock down under
+// matrix load, and lower for v_mfma_f32_32x32x16 than for 16x16x32 -- the same FLOP took 653 ns against 553 ns in bare loops on random
+// data (1.63 against 1.97 GHz; tools/micro/pingpong_probe.hip, profiles/r04_pingpong_probe.log; MI355X guide, DVFS item 7), and
+// in this kernel MFMA time and VALU time ADD (same probe: neither SIMD partners nor one wave's own stream overlap them).
+// Same counts as attn2_kernel per 64 x 64 tile and wave: 8 K fragments, 8 V^T fragment pairs, 64 exp2, 32 packs, 32 dot2; 64 MFMAs of
+// 16 cycles instead of 32 of 32; the -m_run C-operand block is 4 registers per query block instead of 16.
+//   S^T block (16 keys x 16 queries) = K(16 x 32 d) Q^T: lane (i16 = lane & 15, g = lane >> 4) holds keys 4g .. 4g+3 of query i16
+//   P^T as B operand of O^T(16 d x 16 queries) += V^T(16 d x 32 keys) P^T: the 32 keys of a step are two 16-key blocks in the order
+//   kappa = 8g + r <-> key 4g + r of block 2j, kappa = 8g + 4 + r <-> key 4g + r of block 2j + 1: a lane's B fragment is its own
+//   registers of the two blocks, and the V^T fragment is two ds_read_b64_tr_b16 of rows 32j + 4g .. +3 and 32j + 16 + 4g .. +3.
+// K tile: attn_kernel's swizzle (conflict-free for these b128 reads too); V tile: chunk c of row r at c ^ (((r >> 1) & 3) << 1).
+// Not bitwise equal to the 32x32x16 kernels (the MFMA shapes sum their k products in different orders): tested against fp64.
+__device__ __forceinline__ int v16_chunk_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }
+
 template <int KT, bool SPLIT = false>
-__global__ __launch_bounds__(512, 1) void attn4_kernel(AttnArgs p) {
-  constexpr int NW = 8, QB = 2, KB = KT / 32, NBUF = 4;
+__global__ __launch_bounds__(256, 2) void attn16_kernel(AttnArgs p) {
+  constexpr int NW = 4, NQ = 4, NKB = KT / 16, NJ = KT / 32;
+  __shared__ __attribute__((aligned(16))) char smem[3 * 2 * KT * 128];
   constexpr int BUF_BYTES = 2 * KT * 128;
-  __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF_BYTES];
-  static_assert(KT / 8 / NW == 1, "one K and one V piece per wave and tile");
-  constexpr int G = 2;
-  static_assert(NBUF * BUF_BYTES >= NW * QB * 32 * 128, "the output staging re-uses the ring");
+  constexpr int IP = KT / 8 / NW;
+  constexpr int G = 2 * IP;
+  static_assert(3 * BUF_BYTES >= NW * 64 * 128, "the output staging re-uses the ring");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int qi = lane & 31, hh = lane >> 5;
+  const int i16 = lane & 15, g = lane >> 4;
 
   int bid;
   {
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(512, 1) void attn4_kernel(AttnArgs p) {
     const int nt_all = (p.lk + KT - 1) / KT, tps = (nt_all + p.nsplit - 1) / p.nsplit;
     key0 = ksp * tps * KT;
     const int key1 = (ksp + 1) * tps * KT < p.lk ? (ksp + 1) * tps * KT : p.lk;
-    lk = key1 - key0;
+    lk = key1 - key0;  // > 0: the host only splits when every split gets at least one tile
   }
 
   const half_t* const qbase = p.q + b0 * p.q_sb0 + b1 * p.q_sb1 + head * 64;
@@ -815,331 +817,250 @@ __global__ __launch_bounds__(512, 1) void attn4_kernel(AttnArgs p) {
   const half_t* const vbase = p.v + b0 * p.k_sb0 + b1 * p.k_sb1 + head * 64 + (int64_t)key0 * p.k_sl;
   half_t* const obase = p.out + b0 * p.o_sb0 + b1 * p.o_sb1 + head * 64;
 
-  half8_t qf[QB][4];
+  const int wq0 = qb * (64 * NW) + wave * 64;  // first query row of this wave
+  half8_t qf[NQ][2];
 #pragma unroll
-  for (int c = 0; c < QB; ++c) {
-    const int qrow = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c + qi;
+  for (int c = 0; c < NQ; ++c) {
+    const int qrow = wq0 + 16 * c + i16;
     const int qrow_c = qrow < p.lq ? qrow : p.lq - 1;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      qf[c][s] = *(const half8_t*)(qbase + (int64_t)qrow_c * p.q_sl + 16 * s + 8 * hh);
+    for (int ks = 0; ks < 2; ++ks) qf[c][ks] = *(const half8_t*)(qbase + (int64_t)qrow_c * p.q_sl + 32 * ks + 8 * g);
   }
-  // a wave whose 64 query rows all lie past lq keeps feeding the ring and meeting the barriers but computes nothing
-  const bool active = __builtin_amdgcn_readfirstlane(qb * (32 * QB * NW) + wave * (32 * QB)) < p.lq;
-  f32x16 acc_o[QB][2];
-  float m_run[QB], l_run[QB];
-  f32x16 neg_m[QB];
+  // a wave whose 64 query rows all lie past lq keeps feeding the K/V ring and meeting the barriers but computes nothing
+  const bool active = __builtin_amdgcn_readfirstlane(wq0) < p.lq;
+  f32x4 acc_o[NQ][4];  // [query block][16-dim block]: dims 4g .. 4g+3 of query i16
+  float m_run[NQ], l_run[NQ];
+  f32x4 neg_m[NQ];     // -m_run: the C operand of the first score MFMA of every key block
 #pragma unroll
-  for (int c = 0; c < QB; ++c) {
+  for (int c = 0; c < NQ; ++c) {
     m_run[c] = 0.f;
     l_run[c] = 0.f;
+    neg_m[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) neg_m[c][r] = 0.f;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_o[c][d][r] = 0.f;
+    for (int d = 0; d < 4; ++d) acc_o[c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  constexpr float P_SUM_BOUND = 16384.0f;
+  constexpr float P_SUM_BOUND = 16384.0f;  // a lane's partial row sum at or above 2^14: look at the maximum, rescale (as attn2_kernel)
 
   const int nt = (lk + KT - 1) / KT;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int group = wave_u >> 2;  // SIMD partners are waves w and w + 4: group 1 runs one segment behind group 0
   const unsigned smem_base =
       __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
   const int sr = lane >> 3, sp = lane & 7;
-  const half_t* kp;
-  const half_t* vp;
-  {
-    const int row = 8 * wave_u + sr;
+  const half_t* kp[IP];
+  const half_t* vp[IP];
+#pragma unroll
+  for (int i = 0; i < IP; ++i) {
+    const int row = 8 * (wave_u * IP + i) + sr;
     const int key = row < lk ? row : lk - 1;
-    kp = kbase + (int64_t)key * p.k_sl + k_chunk_swz(row, sp) * 8;
-    vp = vbase + (int64_t)key * p.k_sl + v_chunk_swz(row, sp) * 8;
+    kp[i] = kbase + (int64_t)key * p.k_sl + k_chunk_swz(row, sp) * 8;
+    vp[i] = vbase + (int64_t)key * p.k_sl + v16_chunk_swz(row, sp) * 8;
   }
   const int64_t tile_stride = (int64_t)KT * p.k_sl;
   const bool ragged = (lk % KT) != 0;
-  auto issue_tile = [&](int kt) {  // tiles are issued strictly in order 0, 1, 2, ... into buffer kt % NBUF
-    const unsigned dst = smem_base + (kt & (NBUF - 1)) * BUF_BYTES + 8 * wave_u * 128;
-    if (ragged && kt == nt - 1 && kt > 0) {
-      const int row = 8 * wave_u + sr;
-      int key = kt * KT + row;
-      if (key >= lk) key = lk - 1;
-      const int64_t roff = (int64_t)key * p.k_sl;
-      glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
-      glds16_raw(vbase + roff + v_chunk_swz(row, sp) * 8, dst + KT * 128);
-    } else {
-      glds16_raw(kp, dst);
-      glds16_raw(vp, dst + KT * 128);
+  auto issue_tile = [&](int kt, int buf) {  // tiles are issued strictly in order 0, 1, 2, ...
+    const bool clamp = ragged && kt == nt - 1 && kt > 0;
+#pragma unroll
+    for (int i = 0; i < IP; ++i) {
+      const unsigned dst = smem_base + buf * BUF_BYTES + 8 * (wave_u * IP + i) * 128;
+      if (clamp) {
+        const int row = 8 * (wave_u * IP + i) + sr;
+        int key = kt * KT + row;
+        if (key >= lk) key = lk - 1;
+        const int64_t roff = (int64_t)key * p.k_sl;
+        glds16_raw(kbase + roff + k_chunk_swz(row, sp) * 8, dst);
+        glds16_raw(vbase + roff + v16_chunk_swz(row, sp) * 8, dst + KT * 128);
+      } else {
+        glds16_raw(kp[i], dst);
+        glds16_raw(vp[i], dst + KT * 128);
+      }
+      kp[i] += tile_stride;
+      vp[i] += tile_stride;
     }
-    kp += tile_stride;
-    vp += tile_stride;
   };
-  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+  const int q4 = i16 >> 2, p4 = i16 & 3;
   typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
   const fp16x2_t ones2 = {(__fp16)1.0f, (__fp16)1.0f};
 
-  f32x16 sc[QB][KB];       // scores of the tile in flight: written by M_t, consumed by V_t
-  half8_t pf[QB][KB][2];   // its probabilities: written by V_t, consumed by M_(t+1)
-
-  // Fragments are read one segment AHEAD (at the end of the wave's V segment, into the registers the dead scores leave free), so an M
-  // segment is MFMAs only: read right before use they exposed the LDS latency in front of every MFMA pair (M = 1530 - 1780 cycles for
-  // 1024 of MFMA, tools/kattn_stamps.py) -- two independent workgroups cover that for each other, SIMD partners in opposite roles cannot.
-  half8_t kf[KB][4];      // K(t) fragments for the scores of M_t
-  half8_t vf[2][KB][2];   // V^T(t-1) fragments for the P V product of M_t
-  auto read_k = [&](int kt) {
-    const char* const lds_k = smem + (kt & (NBUF - 1)) * BUF_BYTES;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const int krow = 32 * kb + qi;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) kf[kb][s] = *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 2 * s + hh) << 4));
-    }
-  };
-  auto read_v = [&](int kt) {
-    const char* const lds_v = smem + (kt & (NBUF - 1)) * BUF_BYTES + KT * 128;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int r0 = 32 * kb + 16 * s2 + 4 * hh;
-          const int colbyte = (32 * db + 16 * (g16 & 1) + 4 * p4) * 2;
-          const int ch = colbyte >> 4, within = colbyte & 15;
-          const int ra = r0 + q4, rb = r0 + 8 + q4;
-          vf[db][kb][s2] = tr_read_pair(lds_v + ra * 128 + (v_chunk_swz(ra, ch) << 4) + within,
-                                        lds_v + rb * 128 + (v_chunk_swz(rb, ch) << 4) + within);
-        }
-  };
-  auto scores = [&]() {  // S^T(t) = K(t) Q^T, accumulators start at -m_run
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int c = 0; c < QB; ++c) sc[c][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][s], qf[c][s], s == 0 ? neg_m[c] : sc[c][kb], 0, 0, 0);
-  };
-  auto pv = [&]() {  // O^T += V^T(t-1) P^T(t-1)
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int c = 0; c < QB; ++c)
-            acc_o[c][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db][kb][s2], pf[c][kb][s2], acc_o[c][db], 0, 0, 0);
-  };
-  auto softmax = [&](int kt, auto masked_c) {  // attn2_kernel's, statement for statement
+  auto tile = [&](int buf, auto masked_c, int kt) {
     constexpr bool MASKED = decltype(masked_c)::value;
+    const char* const lds_k = smem + buf * BUF_BYTES;
+    const char* const lds_v = lds_k + KT * 128;
+    const bool more2 = kt + 2 < nt;
+    if (more2) issue_tile(kt + 2, buf == 0 ? 2 : buf - 1);  // (buf + 2) % 3
+
+    if (active) {
+      // ---- S^T = K Q^T for the four query blocks off ONE K fragment; accumulators start at -m_run (q carries scale*log2e) ----
+      f32x4 sc[NQ][NKB];
 #pragma unroll
-    for (int c = 0; c < QB; ++c) {
-      if (MASKED) {
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int krow = 16 * kb + i16;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int ks = 0; ks < 2; ++ks) {
+          const half8_t kf = *(const half8_t*)(lds_k + krow * 128 + (k_chunk_swz(krow, 4 * ks + g) << 4));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kt * KT + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (key >= lk) sc[c][kb][r] = -1e30f;
-          }
+          for (int c = 0; c < NQ; ++c)
+            sc[c][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[c][ks], ks == 0 ? neg_m[c] : sc[c][kb], 0, 0, 0);
+        }
       }
-      float ls[4];
-      const auto exp_pack = [&]() {
-        ls[0] = ls[1] = ls[2] = ls[3] = 0.f;
+      // ---- online softmax per query block (attn2_kernel's: exp2 / pack / row sums first, the maximum only on the rare path) ----
+      half8_t pf[NQ][NJ];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+      for (int c = 0; c < NQ; ++c) {
+        if (MASKED) {
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
+          for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kt * KT + 16 * kb + 4 * g + r >= lk) sc[c][kb][r] = -1e30f;
+        }
+        float ls[4];
+        const auto exp_pack = [&]() {
+          ls[0] = ls[1] = ls[2] = ls[3] = 0.f;  // four partial sums: short dependent dot2 chains
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
             fp16x2_t pk[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float e0 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j]);
-              const float e1 = __builtin_amdgcn_exp2f(sc[c][kb][8 * s2 + 2 * j + 1]);
-              pk[j] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
-              ls[j] = __builtin_amdgcn_fdot2(pk[j], ones2, ls[j], false);
-            }
-            pf[c][kb][s2] = __builtin_bit_cast(half8_t, pk);
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const float e0 = __builtin_amdgcn_exp2f(sc[c][2 * j + h][2 * e]);
+                const float e1 = __builtin_amdgcn_exp2f(sc[c][2 * j + h][2 * e + 1]);
+                pk[2 * h + e] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+                ls[2 * h + e] = __builtin_amdgcn_fdot2(pk[2 * h + e], ones2, ls[2 * h + e], false);
+              }
+            pf[c][j] = __builtin_bit_cast(half8_t, pk);
           }
-        return (ls[0] + ls[1]) + (ls[2] + ls[3]);
-      };
-      float tot = exp_pack();
-      const bool first = kt == 0;
-      if (__builtin_expect(first || __any(!(tot < P_SUM_BOUND)), 0)) {
-        float mk[KB];
+          return (ls[0] + ls[1]) + (ls[2] + ls[3]);
+        };
+        float tot = exp_pack();
+        const bool first = kt == 0;
+        if (__builtin_expect(first || __any(!(tot < P_SUM_BOUND)), 0)) {  // wave-uniform, rare (NaN / inf sums land here too)
+          float mx = sc[c][0][0];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          mk[kb] = sc[c][kb][0];
+          for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-          for (int r = 1; r < 16; ++r) mk[kb] = fmaxf(mk[kb], sc[c][kb][r]);
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[c][kb][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));  // the four lanes of a query: lane groups g = 0 .. 3
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float delta = first ? mx : fmaxf(mx, 0.f);
+          const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+          m_run[c] += delta;
+          l_run[c] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) neg_m[c][r] = -m_run[c];
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[c][d][r] *= alpha;
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[c][kb][r] -= delta;
+          tot = exp_pack();
         }
-        float mx = mk[0];
-#pragma unroll
-        for (int kb = 1; kb < KB; ++kb) mx = fmaxf(mx, mk[kb]);
-        mx = half_wave_max(mx);
-        const float delta = first ? mx : fmaxf(mx, 0.f);
-        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-        m_run[c] += delta;
-        l_run[c] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) neg_m[c][r] = -m_run[c];
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc_o[c][d][r] *= alpha;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[c][kb][r] -= delta;
-        tot = exp_pack();
+        l_run[c] += tot;
       }
-      l_run[c] += tot;
-    }
-  };
-  const auto barrier = [&]() {  // a segment boundary: nothing moves across it, neither memory operations nor arithmetic
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+      // ---- O^T += V^T P^T for the four query blocks off ONE V^T fragment ----
+      // all eight V^T fragments are ISSUED before the first MFMA (the scores' registers are free by now): read one pair ahead, as hipcc
+      // orders them, every group of eight MFMAs waits for its LDS round trip.  Same-box A/B (profiles/r04_kattn16.log): per-frame
+      // attention at 72x72 1462 -> 1409 us, joint at 36x36 3429 -> 3401; the same for the K fragments of the score phase changes nothing.
+      half8_t vfa[4][NJ];
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int ra = 32 * j + 4 * g + q4, rb = ra + 16;
+          const int colbyte = (16 * db + 4 * p4) * 2;
+          const int ch = colbyte >> 4, within = colbyte & 15;
+          vfa[db][j] = tr_read_pair(lds_v + ra * 128 + (v16_chunk_swz(ra, ch) << 4) + within,
+                                    lds_v + rb * 128 + (v16_chunk_swz(rb, ch) << 4) + within);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int c = 0; c < NQ; ++c) acc_o[c][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfa[db][j], pf[c][j], acc_o[c][db], 0, 0, 0);
+    }  // active
+    if (more2) wait_vm<G>();
+    else wait_vm<0>();
+    __syncthreads();
   };
 
-  issue_tile(0);
-  if (nt > 1) issue_tile(1);
-  wait_vm<0>();
-#pragma unroll
-  for (int c = 0; c < QB; ++c)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[c][s]));  // retire the Q loads (see attn_kernel)
-  barrier();
-  if (group == 1) barrier();  // the skew: from here on group 1 is one segment behind
-  const int nfull = lk / KT;
-  // V segments run at priority 1: the younger half of the workgroup (waves 4 - 7) otherwise loses the VALU arbitration against its
-  // partner's MFMA stream (V = 1900 cycles against 1080 for the older half); an MFMA needs one issue slot in 32 cycles
-#ifndef SEVA_ATTN4_PRIO
-#define SEVA_ATTN4_PRIO 1
-#endif
-  const auto end_v = [&](int kt) {  // the next M segment's fragments; own DMA pieces (tile kt + 2, issued two segments ago) have landed
-    __builtin_amdgcn_sched_barrier(0);
-    read_v(kt);
-    if (kt + 1 < nt) read_k(kt + 1);
-    if (SEVA_ATTN4_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    wait_vm<0>();
-    barrier();
-    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(1);
-  };
-  const auto end_m = [&]() {
-    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-    barrier();
-    if (SEVA_ATTN4_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-  };
-  if (active) {
-    // sc, pf, kf, vf are written UNCONDITIONALLY in every segment that writes them (a conditional write keeps the old value alive, and
-    // the blocks together do not fit the register file): the idle waves have their own loop
-    read_k(0);
-    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(1);
-    for (int kt = 0; kt < nfull; ++kt) {
-#ifdef SEVA_ATTN_STAMP  // diagnostic build only (tools/kattn_stamps.py): s_memtime at the segment boundaries of tiles 8..15 of workgroup 0
-      const bool stamp = !SPLIT && p.part_o != nullptr && blockIdx.x == 0 && kt >= 8 && kt < 16 && lane == 0;
-      unsigned long long* const st = (unsigned long long*)p.part_o + (wave_u * 8 + (kt - 8)) * 8;
-      if (stamp) st[0] = __builtin_amdgcn_s_memtime();
-#endif
-      if (kt + 2 < nt) issue_tile(kt + 2);
-      if (kt > 0) pv();  // first: pf dies here, before sc is written
-      scores();
-#ifdef SEVA_ATTN_STAMP
-      __builtin_amdgcn_sched_barrier(0);
-      if (stamp) st[1] = __builtin_amdgcn_s_memtime();  // the last MFMA has ISSUED (in order, 32 cycles apart)
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      end_m();
-#ifdef SEVA_ATTN_STAMP
-      if (stamp) st[2] = __builtin_amdgcn_s_memtime();
-#endif
-      softmax(kt, std::false_type{});
-#ifdef SEVA_ATTN_STAMP
-      __builtin_amdgcn_sched_barrier(0);
-      if (stamp) st[3] = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      end_v(kt);
-#ifdef SEVA_ATTN_STAMP
-      if (stamp) st[4] = __builtin_amdgcn_s_memtime();
-#endif
-    }
-    if (nfull < nt) {  // the ragged last tile
-      if (nfull > 0) pv();
-      scores();
-      end_m();
-      softmax(nfull, std::true_type{});
-      end_v(nfull);
-    }
-    pv();
-    if (SEVA_ATTN4_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+  issue_tile(0, 0);
+  if (nt > 1) {
+    issue_tile(1, 1);
+    wait_vm<G>();
   } else {
-    for (int kt = 0; kt < nt; ++kt) {
-      if (kt + 2 < nt) issue_tile(kt + 2);
-      barrier();
-      wait_vm<0>();
-      barrier();
-    }
+    wait_vm<0>();
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (group == 0) barrier();
-  barrier();  // every wave is done reading K/V tiles
+#pragma unroll
+  for (int c = 0; c < NQ; ++c)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(qf[c][ks]));  // retire the Q loads (see attn_kernel)
+  __syncthreads();
+  const int nfull = lk / KT;
+  int buf = 0;
+  for (int kt = 0; kt < nfull; ++kt) {
+    tile(buf, std::false_type{}, kt);
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  if (nfull < nt) tile(buf, std::true_type{}, nfull);
 
+  float l_tot[NQ];
+#pragma unroll
+  for (int c = 0; c < NQ; ++c) {
+    float l = l_run[c];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    l_tot[c] = l;
+  }
   if constexpr (SPLIT) {
+    // partial result: un-normalised O (relative to m_run) as fp32, 16 bytes per lane and 16-dim block, and (m_run, l) per query row
     const int64_t rows_all = (int64_t)gridDim.x / (p.qblocks * p.nsplit) * p.lq;  // batch * heads * lq
     const int64_t row_bh = ((int64_t)batch * p.heads + head) * p.lq;
 #pragma unroll
-    for (int c = 0; c < QB; ++c) {
-      const int qrow = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c + qi;
-      const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
+    for (int c = 0; c < NQ; ++c) {
+      const int qrow = wq0 + 16 * c + i16;
       if (qrow < p.lq) {
         float* const po = p.part_o + ((int64_t)ksp * rows_all + row_bh + qrow) * 64;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            *(f32x4*)(po + 32 * db + 8 * t + 4 * hh) =
-                f32x4{acc_o[c][db][4 * t], acc_o[c][db][4 * t + 1], acc_o[c][db][4 * t + 2], acc_o[c][db][4 * t + 3]};
-        if (hh == 0) {
+        for (int db = 0; db < 4; ++db) *(f32x4*)(po + 16 * db + 4 * g) = acc_o[c][db];
+        if (g == 0) {
           float* const pm = p.part_ml + ((int64_t)ksp * rows_all + row_bh + qrow) * 2;
           pm[0] = m_run[c];
-          pm[1] = l_tot;
+          pm[1] = l_tot[c];
         }
       }
     }
     return;
   }
+  __syncthreads();  // every wave is done reading K/V tiles
+  char* const ow = smem + wave * (64 * 128);
 #pragma unroll
-  for (int c = 0; c < QB; ++c) {
-    const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
-    const float inv = 1.0f / l_tot;
-    char* const ow = smem + (wave * QB + c) * (32 * 128);
+  for (int c = 0; c < NQ; ++c) {
+    const float inv = 1.0f / l_tot[c];
+    const int row = 16 * c + i16;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 4; ++db) {
+      half4_t h;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        half4_t h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[c][db][4 * t + r] * inv);
-        const int d0 = 32 * db + 8 * t + 4 * hh;
-        const int chunk = d0 >> 3, piece = (d0 >> 2) & 1;
-        *(half4_t*)(ow + qi * 128 + ((chunk ^ (qi & 7)) << 4) + (piece << 3)) = h;
-      }
+      for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc_o[c][db][r] * inv);
+      const int d0 = 16 * db + 4 * g;
+      const int chunk = d0 >> 3, piece = (d0 >> 2) & 1;
+      *(half4_t*)(ow + row * 128 + ((chunk ^ (row & 7)) << 4) + (piece << 3)) = h;
+    }
   }
+  // same wave reads back its own image: no workgroup barrier needed, only the LDS round trip
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int c = 0; c < QB; ++c) {
-    const char* const ow = smem + (wave * QB + c) * (32 * 128);
-    const int q0 = qb * (32 * QB * NW) + wave * (32 * QB) + 32 * c;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 8 * i + (lane >> 3), pchunk = lane & 7;
-      const uint4 v = *(const uint4*)(ow + row * 128 + (pchunk << 4));
-      const int lchunk = pchunk ^ (row & 7);
-      if (q0 + row < p.lq) *(uint4*)(obase + (int64_t)(q0 + row) * p.o_sl + lchunk * 8) = v;
-    }
+  for (int i = 0; i < 8; ++i) {
+    const int row = 8 * i + (lane >> 3), pchunk = lane & 7;
+    const uint4 v = *(const uint4*)(ow + row * 128 + (pchunk << 4));
+    const int lchunk = pchunk ^ (row & 7);
+    if (wq0 + row < p.lq) *(uint4*)(obase + (int64_t)(wq0 + row) * p.o_sl + lchunk * 8) = v;
   }
 }
 
@@ -1239,14 +1160,14 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
   const bool pre = d->q_prescaled != 0;
   SEVA_REQUIRE(!pre || use_tr, "attention: q_prescaled is not available on the SEVA_ATTN_NO_TR debug path");
   if (d->lq <= 32) return launch<1, 32>(a, batch, s, use_tr, pre);
-  // Two-query-block kernel (64 queries per wave, K / V fragments shared by both blocks): the default for long sequences
-  // (+3.6 ... +6.2 % at the three long shapes of a step, -1 % at L = 1296).  Knob attn_two: 0 forces attn_kernel, 1 selects this
-  // kernel from lq >= 512, 3 the software-pipelined kernel above (experimental library only).
+  // Long sequences (lq >= 2048): 64 queries per wave, K / V fragments shared by all its query blocks.  Default: attn16_kernel
+  // (v_mfma_f32_16x16x32; -3 ... -7 % against attn2_kernel on the long shapes of a step, same-box, profiles/r04_kattn16.log).
+  // Knob attn_two: 0 forces attn_kernel, 1 / 2 select attn2_kernel (v_mfma_f32_32x32x16, bitwise equal to attn_kernel) from
+  // lq >= 512, 4 selects attn16_kernel from lq >= 512.
   const int two = g_seva_knobs.attn_two;
   if (pre && use_tr && !a.dbg && ((two < 0 && d->lq >= 2048) || ((two == 1 || two == 2 || two == 4) && d->lq >= 512))) {
-    // knob attn_two = 4: the ping-pong kernel (one 8-wave workgroup per CU, 512 queries per K/V tile)
-    const bool pp = two == 4;
-    const int qrows = pp ? 512 : 256;
+    const bool k16 = two == 4 || two < 0;
+    const int qrows = 256;
     AttnArgs args = a;
     args.qblocks = (a.lq + qrows - 1) / qrows;
     const int64_t nb = batch * a.heads * args.qblocks;
@@ -1269,19 +1190,16 @@ extern "C" int seva_attention_f16(const seva_attn_desc* d, seva_stream_t stream)
       args.nsplit = nsplit;
       args.part_o = d->split_ws;
       args.part_ml = d->split_ws + (int64_t)nsplit * rows_all * 64;
-      if (pp) hipLaunchKernelGGL((attn4_kernel<64, true>), dim3((unsigned)(nb * nsplit)), dim3(512), 0, s, args);
+      if (k16) hipLaunchKernelGGL((attn16_kernel<64, true>), dim3((unsigned)(nb * nsplit)), dim3(256), 0, s, args);
       else hipLaunchKernelGGL((attn2_kernel<64, true>), dim3((unsigned)(nb * nsplit)), dim3(256), 0, s, args);
-      int rc = seva_check_launch("attn2_kernel<split>");
+      int rc = seva_check_launch("attn16_kernel / attn2_kernel <split>");
       if (rc) return rc;
       hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((rows_all * 8 + 255) / 256)), dim3(256), 0, s, args, rows_all);
       return seva_check_launch("attn_combine_kernel");
     }
-#ifdef SEVA_ATTN_STAMP
-    args.part_o = d->split_ws;  // stamps of workgroup 0 (8 waves x 8 tiles x 8 words of 8 bytes)
-#endif
-    if (pp) hipLaunchKernelGGL((attn4_kernel<64>), dim3((unsigned)nb), dim3(512), 0, s, args);
+    if (k16) hipLaunchKernelGGL((attn16_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
     else hipLaunchKernelGGL((attn2_kernel<64>), dim3((unsigned)nb), dim3(256), 0, s, args);
-    return seva_check_launch("attn2_kernel");
+    return seva_check_launch("attn16_kernel / attn2_kernel");
   }
   return launch<4, 64>(a, batch, s, use_tr, pre);
 }

@@ -326,14 +326,14 @@ QK_C = 0.125 * 1.4426950408889634
 @pytest.mark.parametrize("B,H,Lq,Lk", [(3, 2, 200, 200), (1, 1, 1701, 1701), (2, 3, 70, 5), (4, 2, 21, 21),
                                        (1, 2, 33, 64), (2, 1, 500, 777), (2, 2, 1024, 900), (1, 3, 777, 1300)])
 @pytest.mark.parametrize("spike", [False, True])
-@pytest.mark.parametrize("two", ["0", "1"])
+@pytest.mark.parametrize("two", ["0", "1", "4"])
 def test_attention_prescaled_q(dev, B, H, Lq, Lk, spike, two, knobs):
     """q already multiplied by scale*log2(e) (what the engine's QKV projection emits): the kernel starts
     its score accumulators at -m_run and exponentiates the MFMA output directly.  `spike` plants, late in
     the key sequence, keys that beat the running maximum by far more than the deferred-rescale threshold
     (rescale branch), and shifts all logits of the first tile far below zero (first-tile reference)."""
     from seva import ops
-    knobs(attn_two=two)  # 0: attn_kernel everywhere, 1: the two-query-block kernel from Lq >= 512
+    knobs(attn_two=two)  # 0: attn_kernel everywhere; from Lq >= 512: 1 = attn2_kernel (32x32x16 MFMA), 4 = attn16_kernel (16x16x32)
     C = 64 * H
     g = torch.Generator().manual_seed(31)
     q = torch.randn((B, Lq, H, 64), generator=g)
@@ -441,11 +441,14 @@ def test_attention_late_key_around_the_rescale_bound(dev, above):
 
 @pytest.mark.parametrize("B,H,L,Lk", [(4, 5, 7000, 1100), (1, 10, 13500, 700), (3, 7, 6950, 640)])
 def test_attention_kernels_round_identically(dev, B, H, L, Lk, knobs):
-    """attn_kernel (32 queries per wave) and the two-query-block kernel (64 per wave, shared K / V fragments) perform the same
-    arithmetic in the same order per query row: their outputs are equal bit for bit, so which of them a launch gets (a rule on
-    lq) does not show in the result.  (Both take the first tile's maximum as the exponent reference; they differ only in WHEN a
-    later, rare rescale happens -- a score 8 above the reference in attn_kernel, a probability near 2^14 in attn2_kernel -- which
-    scores of this spread never reach; test_attention_prescaled_q[spike=True] covers those paths against fp64.)"""
+    """attn_kernel (32 queries per wave) and attn2_kernel (64 per wave, shared K / V fragments), both on v_mfma_f32_32x32x16, perform
+    the same arithmetic in the same order per query row: their outputs are equal bit for bit.  (Both take the first tile's maximum
+    as the exponent reference; they differ only in WHEN a later, rare rescale happens -- a score 8 above the reference in
+    attn_kernel, a probability near 2^14 in attn2_kernel -- which scores of this spread never reach;
+    test_attention_prescaled_q[spike=True] covers those paths against fp64.)  The default long-sequence kernel, attn16_kernel, is
+    the same scheme on v_mfma_f32_16x16x32, whose k products are summed in another order: it agrees with the other two to the
+    rounding of the f16 output and sits at the same distance from fp64; WHICH kernel a launch gets is a rule on lq alone (a
+    per-sample dimension), never on the batch."""
     from seva import ops
     C = 64 * H
     g = torch.Generator().manual_seed(77)
@@ -453,7 +456,7 @@ def test_attention_kernels_round_identically(dev, B, H, L, Lk, knobs):
     k = torch.randn((B, Lk, C), generator=g).half().to(dev)
     v = torch.randn((B, Lk, C), generator=g).half().to(dev)
     outs = []
-    for two in (0, -1):  # attn_kernel everywhere / default (two-query-block kernel from lq >= 2048)
+    for two in (0, 2, -1):  # attn_kernel everywhere / attn2_kernel / default (attn16_kernel from lq >= 2048)
         knobs(attn_two=two)
         o = torch.full((B, L, C), float("nan"), device=dev, dtype=torch.float16)
         ops.attention(q, k, v, o, nb0=B, nb1=1, heads=H, lq=L, lk=Lk, q_strides=(L * C, 0, C), k_strides=(Lk * C, 0, C),
@@ -462,10 +465,13 @@ def test_attention_kernels_round_identically(dev, B, H, L, Lk, knobs):
         assert torch.isfinite(o).all()
         outs.append(o)
     assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2]), "the default is expected to be the 16x16x32 kernel"
+    assert rel_l2(outs[2].float(), outs[0].float()) < 2e-4  # one f16 rounding apart at most, on a few elements
     qh = q[-1:, -300:].cpu().double().view(1, 300, H, 64).transpose(1, 2)
     kh, vh = (t[-1:].cpu().double().view(1, Lk, H, 64).transpose(1, 2) for t in (k, v))
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) * math.log(2.0), -1) @ vh).transpose(1, 2).reshape(1, 300, C)
-    assert rel_l2(outs[1][-1:, -300:].cpu(), ref) < 2e-3
+    e32, e16 = rel_l2(outs[1][-1:, -300:].cpu(), ref), rel_l2(outs[2][-1:, -300:].cpu(), ref)
+    assert e32 < 2e-3 and e16 < 2e-3 and e16 < 1.1 * e32 + 1e-5, (e32, e16)
 
 
 def test_attention_prescaled_temporal(dev):

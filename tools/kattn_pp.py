@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Ping-pong attention (attn4_kernel, knob attn_two = 4: one 8-wave workgroup per CU, SIMD partners one segment apart) against the
-production kernel (attn2_kernel: two independent 4-wave workgroups per CU) on the long attention shapes of a step:
+"""attn16_kernel (knob attn_two = 4: the two-block scheme on v_mfma_f32_16x16x32_f16) against attn2_kernel (32x32x16) on the long
+attention shapes of a step:
 
-    python tools/kattn_pp.py [--iters N] [--rounds R]
+    python tools/kattn_pp.py [--iters N] [--rounds R] [--splits=-1,0]
 
-1. bit-equality of the two kernels (same MFMAs, same accumulation order, same rescale points), also on ragged / short / split cases;
+1. both kernels against an fp64 reference (ragged / short / split / spiked cases): the MFMA shapes sum their k products in different
+   orders, so the two are not bitwise equal to each other; each has to sit at the f16 input / f16 probability error level;
 2. interleaved timing."""
 import argparse
 import os
@@ -45,17 +46,26 @@ def run(qkv, C, B, H, L, knob, ws, split):
     return o
 
 
+def ref64(qkv, C, B, H, L):
+    q, k, v = (qkv[:, i * C:(i + 1) * C].double().view(B, L, H, 64).transpose(1, 2) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * 0.6931471805599453  # q carries scale * log2(e): exp2(s) = exp(s ln 2)
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, C)
+
+
 nbad = 0
 for B, H, L, split, spike in [(3, 2, 512, 0, False), (2, 3, 577, 0, True), (1, 2, 1100, 0, False), (2, 2, 2048 + 65, 2, True), (1, 1, 4096, 3, False),
-                              (1, 2, 6804, -1, True), (5, 5, 5184, 0, False), (2, 1, 640, 4, False), (1, 1, 513, 0, False), (1, 1, 700, 0, True)]:
+                              (1, 2, 6804, -1, True), (2, 5, 5184, 0, False), (2, 1, 640, 4, False), (1, 1, 513, 0, False), (1, 1, 700, 0, True)]:
     qkv, C = make(B, H, L, seed=L, spike=spike)
     ws = torch.empty(ops.attention_split_workspace_numel(B, H, L, 4), device=dev)
-    a = run(qkv, C, B, H, L, 2, ws, split)
-    b = run(qkv, C, B, H, L, 4, ws, split)
-    ok = torch.equal(a, b) and bool(torch.isfinite(b.float()).all())
+    r = ref64(qkv, C, B, H, L)
+    errs = []
+    for knob in (2, 4):
+        o = run(qkv, C, B, H, L, knob, ws, split).double()
+        errs.append((float((o - r).norm() / r.norm()), float((o - r).abs().max()), bool(torch.isfinite(o).all())))
+    ok = all(e[2] and e[0] < 1e-3 for e in errs) and errs[1][0] < 1.3 * errs[0][0] + 1e-5
     nbad += not ok
-    print(f"bitwise B={B} H={H} L={L} split={split} spike={spike}: {'OK' if ok else 'MISMATCH max ' + str(float((a.float() - b.float()).abs().nan_to_num(1e9).max()))}", flush=True)
-print(f"bit-equality: {nbad} mismatches", flush=True)
+    print(f"vs fp64 B={B} H={H} L={L} split={split} spike={spike}: attn2 rel {errs[0][0]:.2e} max {errs[0][1]:.2e} | attn16 rel {errs[1][0]:.2e} max {errs[1][1]:.2e} {'OK' if ok else 'BAD'}", flush=True)
+print(f"accuracy: {nbad} bad cases", flush=True)
 
 
 def timeit(fn, iters):
@@ -70,7 +80,7 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-print("== shape | split | us attn2 (TFLOP/s) | us attn4 ping-pong (TFLOP/s)", flush=True)
+print("== shape | split | us attn2 (TFLOP/s) | us attn16 (TFLOP/s)", flush=True)
 for name, B, H, L, calls in [("ds1 frame", 42, 5, 5184, 5), ("ds2 joint", 2, 10, 27216, 3), ("ds4 joint", 2, 20, 6804, 3), ("ds2 frame", 42, 10, 1296, 2),
                              ("clean 4096", 8, 8, 4096, 0), ("clean 8192", 4, 8, 8192, 0)]:
     qkv, C = make(B, H, L)
