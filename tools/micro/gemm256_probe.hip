@@ -1,0 +1,178 @@
+// Probe for a 256 x 256 GEMM tile on ONE 4-wave workgroup per CU (one wave per SIMD, 512 registers per lane: 256 accumulator registers
+// for a 128 x 128 wave tile + double-buffered fragments), against the production structure (two 4-wave workgroups per CU on 160 x 128 /
+// 160 x 160 tiles, 80 x 64 / 80 x 80 per wave).  Why: under matrix load the chip is power / clock limited and every instruction's cost adds
+// (tools/micro/pingpong_probe.hip); a 128 x 128 wave tile needs 0.25 LDS fragment reads per MFMA instead of 0.40 - 0.45 and 7.8 instead of
+// 12 - 14 KB of LDS-DMA per MFLOP -- the tile the vendor BLAS picks on these shapes (tools/kyardstick_blas.py: MT256x256x64).
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/gemm256_probe.hip -o /tmp/gemm256_probe && /tmp/gemm256_probe
+// C[m][n] = sum_k A[m][k] W[n][k], f16 in, fp32 accumulate, f16 out; K-tile 64 (128-byte LDS rows, source-side XOR swizzle), both operands
+// by LDS-DMA into two 64 KB stages; fragments of k-step u + 1 are read while the 64 MFMAs of k-step u run; one barrier per K-tile.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef _Float16 half_t;
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+static __device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+static __device__ __forceinline__ int xcd_remap(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = bid & 7;
+  return ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+constexpr int BM = 256, BN = 256, BK = 64, STAGE = (BM + BN) * 128;
+
+__global__ __launch_bounds__(256, 1) void gemm256(const half_t* __restrict__ A, const half_t* __restrict__ W, half_t* __restrict__ C, int M, int N, int K,
+                                                  int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, g = lane >> 4;
+  // sibling N-tiles of an M-tile adjacent in the remapped order: one A panel streams through one XCD's L2
+  const int work = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = work / tiles_n, tn = work - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  // DMA: a stage is 64 pieces of 8 rows x 128 B (32 of A, 32 of W); wave w issues pieces w, w + 4, ... of each operand.  The swizzle key
+  // ((row >> 1) & 7) of a lane's row 8 p + sr depends on the piece's parity only, i.e. on the wave: one base pointer per operand and lane
+  const int sr = lane >> 3, sp = lane & 7;
+  const int row0 = 8 * wave + sr;
+  const int swz = sp ^ ((row0 >> 1) & 7);
+  const int arow = m0 + row0;
+  const half_t* pa = A + (long)(arow < M ? arow : M - 1) * K + swz * 8;  // rows past M: clamped (their results are not stored)
+  const half_t* pw = W + (long)(n0 + row0) * K + swz * 8;
+  const long step32 = 32L * K;  // 32 rows further per piece
+  auto issue = [&](int kt) {
+    const unsigned dst = lds0 + (kt & 1) * STAGE + 8 * wave * 128;
+    const half_t* a = pa + (long)kt * BK;
+    const half_t* w = pw + (long)kt * BK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = m0 + row0 + 32 * i;
+      glds16_raw(r < M ? a + i * step32 : a + (long)(M - 1 - (arow < M ? arow : M - 1)) * K, dst + i * 32 * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) glds16_raw(w + i * step32, dst + BM * 128 + i * 32 * 128);
+  };
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8_t fa[2][8], fw[2][8];  // [fragment set][16-row block]: activations (B operand), weights (A operand)
+  auto read_frags = [&](int set, int kt, int ks) {
+    const char* const sa = smem + (kt & 1) * STAGE + (wm * 128) * 128;
+    const char* const sw = smem + (kt & 1) * STAGE + BM * 128 + (wn * 128) * 128;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int row = 16 * b + i16;  // (row >> 1) & 7 is the same in the tile as in the wave's 128-row half
+      const int off = row * 128 + (((4 * ks + g) ^ ((row >> 1) & 7)) << 4);
+      fa[set][b] = *(const half8_t*)(sa + off);
+      fw[set][b] = *(const half8_t*)(sw + off);
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)  // in place, accumulators pinned to the AGPR half (hipcc's allocator otherwise routes 24 of them through a temporary)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[set][i]), "v"(fa[set][j]));
+  };
+  const int nk = K / BK;
+  issue(0);
+  if (nk > 1) {
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    read_frags(1, kt, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt + 1 has landed (own pieces); my reads of tile kt are done
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk) issue(kt + 2);  // into the stage tile kt occupied
+      read_frags(0, kt + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have written their accumulators (asm MFMAs: no compiler hazard handling)
+  // epilogue: lane holds features 16 i + 4 g .. + 3 (rows of D) of row m = 16 j + i16 (column of D)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __builtin_amdgcn_sched_barrier(0);  // one column block at a time: the accumulators leave their registers 32 at a time, not all at once
+    const int m = m0 + wm * 128 + 16 * j + i16;
+    if (m < M) {
+      half_t* const c = C + (long)m * N + n0 + wn * 128 + 4 * g;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        half4_t h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)acc[i][j][r];
+        *(half4_t*)(c + 16 * i) = h;
+      }
+    }
+  }
+}
+
+int main() {
+  struct Shape { const char* name; int M, N, K; } shapes[] = {{"ds2 geglu", 54432, 5120, 640}, {"ds4 geglu", 13608, 10240, 1280}, {"ds2 qkv", 54432, 1920, 640},
+                                                               {"ds4 ff2", 13608, 1280, 5120}, {"ds1 geglu", 217728, 2560, 320}, {"check", 700, 512, 192}};
+  CK(hipFuncSetAttribute((const void*)gemm256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  for (const Shape& s : shapes) {
+    const long M = s.M, N = s.N, K = s.K;
+    if (N % BN != 0 && N % 256 != 0) { printf("%s: N %% 256 != 0, skipped\n", s.name); continue; }
+    std::vector<half_t> ha(M * K), hw(N * K);
+    srand(11);
+    for (auto& v : ha) v = (half_t)((rand() % 2001 - 1000) / 1000.f);
+    for (auto& v : hw) v = (half_t)((rand() % 2001 - 1000) / 4000.f);
+    half_t *A, *W, *C;
+    CK(hipMalloc(&A, M * K * 2)); CK(hipMalloc(&W, N * K * 2)); CK(hipMalloc(&C, M * N * 2));
+    CK(hipMemcpy(A, ha.data(), M * K * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), N * K * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(C, 0xff, M * N * 2));
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)(N / BN);
+    auto launch = [&]() { hipLaunchKernelGGL(gemm256, dim3(tiles_m * tiles_n), dim3(256), 2 * STAGE, 0, A, W, C, (int)M, (int)N, (int)K, tiles_m, tiles_n); };
+    launch();
+    CK(hipDeviceSynchronize());
+    // spot check against the host
+    std::vector<half_t> hc(M * N);
+    CK(hipMemcpy(hc.data(), C, M * N * 2, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int t = 0; t < 400; ++t) {
+      const long m = (t * 7919L + (t % 3 == 0 ? M - 1 - t : t * 131L)) % M, n = (t * 104729L + 17) % N;
+      double ref = 0;
+      for (long k = 0; k < K; ++k) ref += (double)ha[m * K + k] * (double)hw[n * K + k];
+      const double err = fabs((double)hc[m * N + n] - ref) / (fabs(ref) + 1.0);
+      if (err > worst) worst = err;
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 10; ++i) launch();
+      CK(hipEventRecord(e1));
+      CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms / 10 < best) best = ms / 10;
+    }
+    printf("%-10s M %6ld N %5ld K %4ld | %4d tiles = %.2f rounds of 256 | %8.1f us %7.1f TFLOP/s | worst rel err of 400 samples %.1e\n", s.name, M, N, K,
+           tiles_m * tiles_n, tiles_m * tiles_n / 256.0, best * 1e3, 2.0 * M * N * K / best / 1e9, worst);
+    CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C));
+  }
+  return 0;
+}
