@@ -19,7 +19,7 @@ import re
 # kernel names: gemm_kernel<BM, BN, MODE, EPI, DBG> (MODE 0 plain / 1 conv3x3), attn_kernel<NW, KT, ...>
 CLASSES = {"gemm": re.compile(r"gemm_kernel<(64|128|160), (128|160), 0, |ff_fused"),
            "conv": re.compile(r"gemm_kernel<(64|128|160), (128|160), [123], |conv_win_kernel"),
-           "attention": re.compile(r"attn_kernel<4, 64|attn2_kernel")}
+           "attention": re.compile(r"attn_kernel<4, 64|attn2_kernel|attn16_kernel")}
 
 
 def load(d, counter):
