@@ -84,10 +84,13 @@ typedef struct seva_gemm_desc {
   int64_t ldo8;
   /* optional (NULL = off): GroupNorm statistics of out_f32, emitted by the epilogue while the values are in registers,
    * so that the GroupNorm consuming this tensor (seva_groupnorm_desc.stats1 / stats2) needs no statistics pass over it.
-   * float [ceil(M / 64)][2][N]: for every block of 64 consecutive output rows (aligned to multiples of 64 rows of the
-   * whole tensor) and every output channel, the sum ([..][0][n]) and the sum of squares ([..][1][n]) of the fp32 values
-   * stored (after bias / row_add / residual); rows >= M contribute nothing.  Per channel, so any grouping or channel
-   * concatenation can be formed by the consumer.  Plain epilogue with out_f32 and N >= 128 only; forces 128-row tiles. */
+   * float [ceil(M / 64)][2][N]: for every block of 64 output rows and every output channel, the sum ([..][0][n]) and the
+   * sum of squares ([..][1][n]) of the fp32 values stored (after bias / row_add / residual); rows >= M contribute
+   * nothing.  A block is 64 consecutive rows aligned to multiples of 64 rows of the whole tensor, EXCEPT for 3x3
+   * convolutions over images at least 144 pixels wide with N % 160 != 0 (the 2-D tiles of the window-staged kernel, round
+   * 4), where the blocks [i * hw / 64, (i + 1) * hw / 64) partition the pixels of image i in tile order: consumers must
+   * only rely on the blocks of an image adding up to that image (seva_groupnorm does).  Per channel, so any grouping or
+   * channel concatenation can be formed by the consumer.  Plain epilogue with out_f32 and N >= 128 only; forces 128-row tiles. */
   float* ch_stats;
   /* optional (NULL = off) workspace that lets seva_gemm_f16 run a convolution over small images (<= 128 output pixels per
    * sample, K >= 1024: the 9x9 level of a 576x576 step) as split-K = 2 on 128-row tiles: two workgroups per tile, the

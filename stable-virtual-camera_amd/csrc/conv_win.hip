@@ -24,6 +24,12 @@
 // statistics from the epilogue.  The window's swizzle key is the WINDOW pixel index, so a tap shift that is not a multiple
 // of 16 leaves some 2-way bank conflicts on the A fragment reads (measured: see DESIGN.md section 4).
 //
+// Wide images (the VAE decoder's 144 .. 576 px rows: a linear window of BM pixels + two image rows does not fit LDS): 2-D tiles of
+// 16 output columns x BM / 16 output rows (TW = 16).  The window is the tile's (rows + 2) x 18 source pixels stored row after row
+// (row pitch 18), MFMA block i of the tile is its row i, the tap shift is ky * 18 + kx -- the same uniform scalar -- and the halo costs
+// 27 % more pixels than the tile has whatever the image width.  GroupNorm statistics blocks are then 4 tile rows x 16 pixels (any
+// partition of an image's pixels into 64-pixel blocks serves the consumer, which sums the blocks of an image).
+//
 // NW = 4: two workgroups per CU (the window single-buffered: 320 px + two 160-row weight stages = 80 KiB each).
 // NW = 8: one workgroup per CU on a 256-row tile, window double-buffered and refilled piece by piece under the taps.
 #include "gemm_common.h"
@@ -36,19 +42,26 @@ namespace {
 constexpr int BK = 64;  // fp16 elements per K-tile -> 128-byte LDS rows
 
 struct ConvWinGeom {
-  uint32_t mul_hw, mul_iw, mul_sp, mul_wp;  // floor(2^32 / d) + 1: x / d == mulhi(x, mul) for x * d < 2^32 (host-checked)
+  uint32_t mul_hw, mul_iw, mul_sp, mul_wp;  // floor(2^32 / d) + 1: x / d == mulhi(x, mul) over the launch's range of x (host-checked)
   int32_t Wp, Sp, hw;                       // hw = OUTPUT pixels per image; mul_iw divides by the OUTPUT width ow
   int32_t ow;
   int32_t tiles_m, tiles_n;
   int32_t tpi;  // 0: M-tiles are consecutive BM-pixel ranges of the whole batch; > 0: tiles per image (a tile never leaves its image)
+  int32_t lin_ok;  // host only: the multiply-high divisions of the linear tiles are exact for this launch
 };
 
 // UP: the conv input is the nearest-2x upsampled image (reference layers.py:35-46: F.interpolate(scale_factor=2) then conv): the window
 // is staged from the SOURCE image and tap (ky, kx) of output pixel (y, x) reads source pixel ((y + ky - 1) >> 1, (x + kx - 1) >> 1)
 // (A third weight stage with a counted vmcnt -- tap g + 2 issued under tap g, this tap's own DMA left in flight across the barrier -- was
 // built and measured on the 8-wave family: 3 - 10 % SLOWER on every shape, profiles/r04_kconvwin_variants.log; removed.)
-template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false>
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false, int TW = 0>
 __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWinGeom g) {
+  constexpr bool T2D = TW > 0;
+  static_assert(TW == 0 || TW == 16, "2-D tiles are 16 output columns wide: an MFMA block is a tile row");
+  constexpr int TH = BM / 16;                                  // output rows of a 2-D tile
+  constexpr int SW2 = UP ? 8 : 16, SH2 = UP ? TH / 2 : TH;     // its source extent; window = (SH2 + 2) x (SW2 + 2) pixels
+  constexpr int PITCH2 = SW2 + 2, WL2 = (SH2 + 2) * PITCH2;
+  static_assert(!T2D || (WL2 <= WCAP && TH % 2 == 0), "2-D window capacity");
   constexpr int WMW = NW / 2, WNW = 2;
   constexpr int WM = BM / WMW, WN = BN / WNW;  // per-wave tile
   constexpr int MI = WM / 16, NJ = WN / 16;
@@ -74,9 +87,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
 
   const int work = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
   const int tm = work / g.tiles_n, tn = work - tm * g.tiles_n;  // sibling N-tiles of an M-tile are neighbours on one XCD
-  // rows [m0, m_end) of the [M][N] output belong to this tile
+  // rows [m0, m_end) of the [M][N] output belong to this tile (2-D tiles: BM rows of ONE image that are not consecutive; see row_m)
   uint32_t m0, m_end;
-  if (g.tpi > 0) {
+  uint32_t t_img = 0, t_y0 = 0, t_x0 = 0, t_k = 0;  // 2-D: image, output origin of the tile, tile number inside the image
+  if constexpr (T2D) {
+    t_img = (uint32_t)tm / (uint32_t)g.tpi;
+    t_k = (uint32_t)tm - t_img * (uint32_t)g.tpi;
+    const uint32_t tpr = (uint32_t)g.ow / 16u, ty = t_k / tpr;
+    t_y0 = ty * TH;
+    t_x0 = (t_k - ty * tpr) * 16u;
+    m0 = t_img * (uint32_t)g.hw;
+    m_end = m0 + (uint32_t)g.hw;
+  } else if (g.tpi > 0) {
     const uint32_t img = (uint32_t)tm / (uint32_t)g.tpi, k = (uint32_t)tm - img * (uint32_t)g.tpi;
     m0 = img * (uint32_t)g.hw + k * BM;
     m_end = m0 + BM < (img + 1) * (uint32_t)g.hw ? m0 + BM : (img + 1) * (uint32_t)g.hw;
@@ -85,6 +107,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
     m_end = m0 + BM < (uint32_t)p.M ? m0 + BM : (uint32_t)p.M;
   }
   const int64_t n0 = (int64_t)tn * BN;
+  // output row of MFMA block i (of this wave) and lane fr; linear tiles: may lie past the tile (m >= m_end: clamp for loads, no store)
+  auto row_m = [&](int i) -> uint32_t {
+    if constexpr (T2D) return m0 + (t_y0 + (uint32_t)(wm * (WM / 16) + i)) * (uint32_t)g.ow + t_x0 + (uint32_t)fr;
+    else return m0 + (uint32_t)(wm * WM + 16 * i + fr);
+  };
+  const int pitch = T2D ? PITCH2 : g.Wp;  // window row pitch
 
   // padded index of the source pixel under the CENTRE tap of output pixel m (UP: of the pixel it is upsampled from); xo = its column
   auto pad_index = [&](uint32_t m, uint32_t& yo, uint32_t& xo) -> uint32_t {
@@ -95,12 +123,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
     const uint32_t y = UP ? yo >> 1 : yo, x = UP ? xo >> 1 : xo;
     return img * (uint32_t)g.Sp + (y + 1) * (uint32_t)g.Wp + x + 1;
   };
-  uint32_t y_a, x_a, y_b, x_b;
-  const uint32_t P0 = pad_index(m0, y_a, x_a), P1 = pad_index(m_end - 1, y_b, x_b);
-  // window = [first source pixel any tap reads, last one]: plain conv: consecutive pixels, one halo of Wp + 1 on either side;
-  // UP: output rows 2r and 2r + 1 read the same source row, so the window holds whole source rows (first row's start .. last row's end)
-  const uint32_t q0 = (UP ? P0 - (x_a >> 1) : P0) - (uint32_t)(g.Wp + 1);   // padded index of window pixel 0
-  const int WL = (int)((UP ? P1 - (x_b >> 1) + (uint32_t)p.iw - 1 : P1) - q0) + g.Wp + 2;  // window pixels this tile reads (<= WCAP)
+  uint32_t q0 = 0;
+  int WL = WL2;
+  if constexpr (!T2D) {
+    uint32_t y_a, x_a, y_b, x_b;
+    const uint32_t P0 = pad_index(m0, y_a, x_a), P1 = pad_index(m_end - 1, y_b, x_b);
+    // window = [first source pixel any tap reads, last one]: plain conv: consecutive pixels, one halo of Wp + 1 on either side;
+    // UP: output rows 2r and 2r + 1 read the same source row, so the window holds whole source rows (first row's start .. last row's end)
+    q0 = (UP ? P0 - (x_a >> 1) : P0) - (uint32_t)(g.Wp + 1);   // padded index of window pixel 0
+    WL = (int)((UP ? P1 - (x_b >> 1) + (uint32_t)p.iw - 1 : P1) - q0) + g.Wp + 2;  // window pixels this tile reads (<= WCAP)
+  }
   const int npc = __builtin_amdgcn_readfirstlane((WL + 7) >> 3);
 
   // ---- window fill: lane (pixel 8 pc + sr, physical chunk sp) of piece pc fetches logical chunk sp ^ key(pixel) ----
@@ -109,20 +141,32 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   for (int i = 0; i < PPW; ++i) {
     const int pc = i * NW + wave;
     const int j = 8 * pc + sr;
-    const uint32_t q = q0 + (uint32_t)j;
-    const uint32_t img = __umulhi(q, g.mul_sp);
-    const uint32_t rem = q - img * (uint32_t)g.Sp;
-    const uint32_t py = __umulhi(rem, g.mul_wp);
-    const uint32_t px = rem - py * (uint32_t)g.Wp;
-    const bool ok = (img < (uint32_t)p.n) & (py >= 1u) & (px >= 1u) & (j < WL);  // row 0 / column 0 of an image block are frame cells
     const int chunk = sp ^ ((j >> 1) & 7);
-    const uint32_t pix = (img * (uint32_t)p.ih + (py - 1)) * (uint32_t)p.iw + (px - 1);
+    bool ok;
+    uint32_t pix;
+    if constexpr (T2D) {  // window pixel j = (wy, wx) of the (SH2 + 2) x PITCH2 block around the tile's source pixels
+      const int wy = j / PITCH2, wx = j - wy * PITCH2;
+      const int sy = (int)(UP ? t_y0 >> 1 : t_y0) - 1 + wy, sx = (int)(UP ? t_x0 >> 1 : t_x0) - 1 + wx;
+      ok = (j < WL2) & (sy >= 0) & (sy < p.ih) & (sx >= 0) & (sx < p.iw);
+      pix = (uint32_t)sy * (uint32_t)p.iw + (uint32_t)sx;  // inside the tile's image: its base is added as a 64-bit scalar (a_img)
+    } else {
+      const uint32_t q = q0 + (uint32_t)j;
+      const uint32_t img = __umulhi(q, g.mul_sp);
+      const uint32_t rem = q - img * (uint32_t)g.Sp;
+      const uint32_t py = __umulhi(rem, g.mul_wp);
+      const uint32_t px = rem - py * (uint32_t)g.Wp;
+      ok = (img < (uint32_t)p.n) & (py >= 1u) & (px >= 1u) & (j < WL);  // row 0 / column 0 of an image block are frame cells
+      pix = (img * (uint32_t)p.ih + (py - 1)) * (uint32_t)p.iw + (px - 1);
+    }
     woff[i] = ok ? (int)((pix * (uint32_t)p.cin + (uint32_t)chunk * 8u) * 2u) : -1;
   }
+  // 2-D tiles: offsets are relative to the tile's image, so nothing here depends on the batch size (whether this kernel runs must be a
+  // function of per-sample dimensions only: per-frame results are then identical whatever the number of frames per pass)
+  const char* const a_img = (const char*)p.a + (T2D ? (int64_t)t_img * p.ih * p.iw * p.cin * 2 : (int64_t)0);
   auto fill_piece = [&](int i, int s, int wb) {  // i: compile-time after unrolling
     const int pc = i * NW + wave;
     if (pc < npc) {  // wave-uniform
-      const char* const src = woff[i] >= 0 ? (const char*)p.a + (int64_t)s * 128 + woff[i] : (const char*)g_zero_page;
+      const char* const src = woff[i] >= 0 ? a_img + (int64_t)s * 128 + woff[i] : (const char*)g_zero_page;
       glds16_raw(src, lds_base_u32 + wb * WIN_BYTES + pc * 1024);
     }
   };
@@ -161,17 +205,26 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   int a_base[MI], a_rm[UP ? MI : 1], a_rp[UP ? MI : 1], a_xp[UP ? MI : 1];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    uint32_t m = m0 + wm * WM + 16 * i + fr, yo, xo;
-    if (m >= m_end) m = m_end - 1;
-    const int ctr = (int)(pad_index(m, yo, xo) - q0);
+    int ctr, yp, xp;  // window pixel under the centre tap; (UP) row / column parity of the output pixel
+    if constexpr (T2D) {
+      const int row = wm * (WM / 16) + i;  // tile row = MFMA block
+      ctr = UP ? ((row >> 1) + 1) * PITCH2 + (fr >> 1) + 1 : (row + 1) * PITCH2 + fr + 1;
+      yp = row & 1;  // the tile's origin is even in both directions
+      xp = fr & 1;
+    } else {
+      uint32_t m = row_m(i), yo, xo;
+      if (m >= m_end) m = m_end - 1;
+      ctr = (int)(pad_index(m, yo, xo) - q0);
+      yp = (int)(yo & 1);
+      xp = (int)(xo & 1);
+    }
     if constexpr (UP) {
-      const int yp = (int)(yo & 1), xp = (int)(xo & 1);
       a_base[i] = ctr;
-      a_rm[i] = ctr + (yp - 1) * g.Wp;
-      a_rp[i] = ctr + yp * g.Wp;
+      a_rm[i] = ctr + (yp - 1) * pitch;
+      a_rp[i] = ctr + yp * pitch;
       a_xp[i] = xp;
     } else {
-      a_base[i] = ctr - g.Wp - 1;
+      a_base[i] = ctr - pitch - 1;
     }
   }
 
@@ -183,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   if (p.residual) {  // the residual tile goes straight into the accumulators (clamped addresses; stores are guarded)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      int64_t m = (int64_t)m0 + wm * WM + 16 * i + fr;
+      int64_t m = row_m(i);
       if (m >= m_end) m = m_end - 1;
       const float* rp = p.residual + m * p.ldr;
 #pragma unroll
@@ -221,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
         if (more && t < PPW) fill_piece(t, s + 1, (s + 1) & 1);
       }
       const char* const tb = lds_b + cur * B_BYTES;
-      int toff = UP ? 0 : (t / 3) * g.Wp + (t % 3);
+      int toff = UP ? 0 : (t / 3) * pitch + (t % 3);
       asm volatile("" : "+s"(toff));  // opaque: the nine taps' fragment addresses are formed here, not hoisted out of the slab loop (45 registers)
       // fragment reads + MFMAs of the tap.  FIRST: every fragment read is ISSUED before the first MFMA (hipcc otherwise re-uses one
       // register quad for the second k-step's window fragments and waits for each read right in front of the five MFMAs that need it:
@@ -289,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int64_t m = (int64_t)m0 + wm * WM + 16 * i + fr;
+    const int64_t m = row_m(i);
     const int64_t mc = m < m_end ? m : m_end - 1;
     f32x4 v[NJ];
 #pragma unroll
@@ -317,14 +370,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   }
   if constexpr (STATS) {
     if (p.ch_stats != nullptr) {  // per 64-row block and channel: sum and sum of squares (gemm.hip, same association)
+      // block number: linear tiles: 64 consecutive rows of the tensor; 2-D tiles: the wave's 4 tile rows x 16 pixels, numbered inside the image
       const int64_t mw = (int64_t)m0 + wm * WM;
-      float* const sp_ = p.ch_stats + (mw >> 6) * 2 * p.N;
+      const int64_t blk = T2D ? (int64_t)t_img * (g.hw >> 6) + (int64_t)t_k * (BM / 64) + wm : mw >> 6;
+      float* const sp_ = p.ch_stats + blk * 2 * p.N;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, qsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const f32x4 vm = mw + 16 * i + fr < m_end ? acc[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the tile contribute nothing
+          const f32x4 vm = (T2D || mw + 16 * i + fr < m_end) ? acc[i][j] : f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the tile contribute nothing
           ssum += vm;
           qsum += vm * acc[i][j];
         }
@@ -334,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
           qsum[r] = row16_sum(qsum[r]);
         }
         const int64_t f = n0 + wn * WN + 16 * j + 4 * fg;
-        if (fr == 0 && mw < m_end && f < p.N) {
+        if (fr == 0 && (T2D || mw < m_end) && f < p.N) {
           *(f32x4*)(sp_ + f) = ssum;
           *(f32x4*)(sp_ + p.N + f) = qsum;
         }
@@ -345,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
 
 uint32_t magic_u32(uint32_t d) { return (uint32_t)(0x100000000ull / d) + 1u; }
 
-template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false>
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false, int TW = 0>
 int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
   constexpr int lds = (DBW ? 2 : 1) * WCAP * 128 + 2 * BN * 128;
   static_assert(lds <= 160 * 1024, "LDS per workgroup");
@@ -354,11 +409,19 @@ int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
-    (void)hipFuncSetAttribute((const void*)conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_devs.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   ConvWinGeom g = g0;
   g.tiles_n = (int)((a.N + BN - 1) / BN);
+  if constexpr (TW > 0) {
+    // 2-D tiles: whole tiles only, and (statistics) whole 64-pixel blocks per image
+    constexpr int TH = BM / 16;
+    if (a.ow % 16 != 0 || a.oh % TH != 0 || g.hw % 64 != 0) return 1;
+    g.tpi = (a.oh / TH) * (a.ow / 16);
+    g.tiles_m = a.n * g.tpi;
+  } else {
+  if (!g.lin_ok) return 1;
   // the widest window any tile needs must fit the instantiation's capacity: consecutive pixels of the whole batch if that fits
   // (a tile may then straddle images), else consecutive pixels of one image, else the launch is not for this kernel
   const auto window_len = [&](int64_t ma, int64_t mb) {  // the kernel's WL for output rows [ma, mb]
@@ -384,21 +447,23 @@ int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
     return wl_max;
   };
   const int tpi = (g.hw + BM - 1) / BM;
-  if (widest(0) <= WCAP) {
+  // (the scan over the tiles of the whole batch is bounded: a window of BM pixels + two rows cannot fit once a row exceeds the capacity)
+  if (g.Wp + 1 <= WCAP && (int64_t)a.M / BM <= 65536 && widest(0) <= WCAP) {
     g.tpi = 0;
     g.tiles_m = (int)((a.M + BM - 1) / BM);
-  } else if (widest(tpi) <= WCAP && !(a.ch_stats != nullptr && g.hw % 64 != 0)) {  // (statistics: 64-row blocks of the WHOLE tensor)
+  } else if (g.Wp + 1 <= WCAP && widest(tpi) <= WCAP && !(a.ch_stats != nullptr && g.hw % 64 != 0)) {  // (statistics: 64-row blocks of the WHOLE tensor)
     g.tpi = tpi;
     g.tiles_m = a.n * tpi;
   } else {
-    return 1;  // not applicable: the caller falls back to the per-tap gather
+    return 1;  // not applicable: the caller tries 2-D tiles, then falls back to the per-tap gather
+  }
   }
   const int64_t nb = (int64_t)g.tiles_m * g.tiles_n;
   if (nb <= 0 || nb > 0x7fffffff) {
     seva_set_error("conv_win: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  hipLaunchKernelGGL((conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP>), dim3((unsigned)nb), dim3(64 * NW), lds, s, a, g);
+  hipLaunchKernelGGL((conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP, TW>), dim3((unsigned)nb), dim3(64 * NW), lds, s, a, g);
   return seva_check_launch("conv_win_kernel");
 }
 
@@ -411,21 +476,42 @@ int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
   if (a.stride != 1 || a.pad_lo != 1 || a.a2 != nullptr || a.sk_ws != nullptr) return 1;
   const int up = a.upsample ? 2 : 1;
   if (a.oh != up * a.ih || a.ow != up * a.iw || a.iw < 2 || a.ih < 2) return 1;
-  if (a.cin % 64 != 0 || a.N % 160 != 0 || a.K != 9LL * a.cin) return 1;
+  if (a.cin % 64 != 0 || (a.N % 160 != 0 && a.N % 128 != 0) || a.K != 9LL * a.cin) return 1;
   ConvWinGeom g{};
   g.Wp = a.iw + 1;             // padded SOURCE space (UP: the image before the nearest-2x upsample)
   g.Sp = (a.ih + 1) * g.Wp;
   g.hw = a.oh * a.ow;
   g.ow = a.ow;
-  // exactness of the multiply-high divisions (x * d < 2^32) and 31-bit byte offsets into the image
+  // 31-bit byte offsets into the image; exactness of the multiply-high divisions of the LINEAR tiles (2-D tiles divide by constants
+  // only): mulhi(x, floor(2^32 / d) + 1) == x / d for every x with x * e < 2^32, e = (floor(2^32 / d) + 1) * d - 2^32 in (0, d]
+  if ((uint64_t)a.ih * a.iw * a.cin * 2 >= (1ull << 31)) return 1;  // one image
+  const auto div_exact = [](uint64_t x_max, uint32_t d) {
+    const uint64_t e = (uint64_t)magic_u32(d) * d - (1ull << 32);
+    return x_max < (1ull << 32) && x_max * e < (1ull << 32);
+  };
   const uint64_t q_max = (uint64_t)a.n * g.Sp + 1024;
-  if (q_max * (uint64_t)g.Sp >= (1ull << 32) || (uint64_t)a.M * (uint64_t)g.hw >= (1ull << 32)) return 1;
-  if ((uint64_t)a.n * a.ih * a.iw * a.cin * 2 >= (1ull << 31)) return 1;
+  g.lin_ok = (uint64_t)a.n * a.ih * a.iw * a.cin * 2 < (1ull << 31) && div_exact((uint64_t)a.M, (uint32_t)g.hw) &&
+             div_exact((uint64_t)g.hw, (uint32_t)g.ow) && div_exact(q_max, (uint32_t)g.Sp) && div_exact((uint64_t)g.Sp, (uint32_t)g.Wp);
   g.mul_hw = magic_u32((uint32_t)g.hw);
   g.mul_iw = magic_u32((uint32_t)g.ow);
   g.mul_sp = magic_u32((uint32_t)g.Sp);
   g.mul_wp = magic_u32((uint32_t)g.Wp);
   const bool stats = a.ch_stats != nullptr;
+  if (a.N % 160 != 0) {
+    // 128-column family (the VAE's 128 / 256 / 512 channels): linear tiles where the window fits (72 px rows), else 2-D tiles of 16 output
+    // columns (144 .. 576 px rows).  Two 4-wave workgroups per CU on 128-row tiles: 2 - 11 % faster than the 8-wave 256-row tile on every
+    // decoder shape (profiles/r04_kconvwin_vae.log), which stays behind knob conv_win = 2.
+    const bool eight = knob == 2;
+    int rc;
+    if (a.upsample) {
+      rc = eight ? launch_win<256, 128, 8, 416, true, true, true>(a, g, s) : launch_win<128, 128, 4, 288, false, true, true>(a, g, s);
+      if (rc == 1) rc = eight ? launch_win<256, 128, 8, 104, true, true, true, 16>(a, g, s) : launch_win<128, 128, 4, 64, false, true, true, 16>(a, g, s);
+    } else {
+      rc = eight ? launch_win<256, 128, 8, 416, true, true>(a, g, s) : launch_win<128, 128, 4, 288, false, true>(a, g, s);
+      if (rc == 1) rc = eight ? launch_win<256, 128, 8, 328, true, true, false, 16>(a, g, s) : launch_win<128, 128, 4, 184, false, true, false, 16>(a, g, s);
+    }
+    return rc;
+  }
   if (a.upsample) {
     // fused nearest-2x upsample (the three Upsample convs of a step): the window over the SOURCE image is small (a quarter of the pixels),
     // the 8-wave 256-row tile always fits; the 4-wave family serves launches too small to fill the CUs with 256-row tiles

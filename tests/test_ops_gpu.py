@@ -249,6 +249,58 @@ def test_conv3x3_window_kernel(dev, n, ih, iw, cin, cout, stats, up, knobs):
     assert rel_l2(outs[1], outs[0]) < 3e-6
 
 
+WIN128_CASES = [  # n, ih, iw, cin, cout, fused nearest-2x upsample: the 128-column family (the VAE's channel counts)
+    (2, 72, 72, 64, 128, False), (1, 144, 144, 64, 256, False), (3, 32, 48, 64, 128, False), (1, 160, 96, 128, 128, False), (1, 288, 288, 64, 128, False),
+    (2, 16, 16, 64, 384, False), (2, 72, 72, 64, 128, True), (1, 144, 144, 64, 128, True), (3, 24, 40, 64, 256, True), (2, 8, 8, 128, 128, True),
+]
+
+
+@pytest.mark.parametrize("n,ih,iw,cin,cout,up", WIN128_CASES)
+def test_conv3x3_window_kernel_128_columns_and_2d_tiles(dev, n, ih, iw, cin, cout, up, knobs):
+    """The window-staged conv on the VAE decoder's shapes (reference seva/modules/autoencoder.py -> diffusers AutoencoderKL decoder convs):
+    N % 128 == 0 instantiations, linear tiles while the window of consecutive pixels fits LDS (72 px rows), 2-D tiles of 16 output
+    columns x 8 / 16 rows from 144 px rows (and wherever the linear window is too wide, e.g. 160 x 96), plain and with the fused
+    nearest-2x upsample.  Integer data: bit-exact against torch for the default dispatch and both families, fp32 and f16 outputs,
+    residual; GroupNorm statistics: the blocks of an image add up to that image's sums (with 2-D tiles a block is 4 tile rows x 16
+    pixels, not 64 consecutive rows).  Random data: one frame of a batch is bitwise the frame computed alone (the kernel choice and
+    the tiling depend on per-sample dimensions only), and the result differs from the per-tap kernel by summation order only."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    sc = 2 if up else 1
+    hw = ih * iw * sc * sc
+    M = n * hw
+    x = _ints((n, cin, ih, iw), -3, 3, dev, 11)
+    w = _ints((cout, cin, 3, 3), -2, 2, dev, 12)
+    bias, res = _ints((cout,), -4, 4, dev, 13), _ints((n, hw, cout), -5, 5, dev, 15)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, bias, padding=1).permute(0, 2, 3, 1).reshape(n, hw, cout) + res
+    xh, wp = x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w)
+    for fam in (-1, 1, 2):
+        knobs(conv_win=fam)
+        out = torch.full((n, hw, cout), float("nan"), device=dev)
+        o16 = torch.full((n, hw, cout), float("nan"), device=dev, dtype=torch.float16)
+        st = torch.full(ops.channel_stats_shape(M, cout), float("nan"), device=dev)
+        ops.conv3x3(xh, wp, upsample=up, bias=bias, residual=res, out_f32=out, out_f16=o16, ch_stats=st)
+        assert torch.equal(out, ref), f"family {fam}: max diff {(out - ref).abs().max()}"
+        assert torch.equal(o16, ref.half())
+        nb = hw // 64
+        assert torch.equal(st[:, 0].view(n, nb, cout).sum(1), ref.sum(1))
+        assert torch.allclose(st[:, 1].view(n, nb, cout).double().sum(1), (ref.double() ** 2).sum(1), rtol=1e-6, atol=0)
+    xr, wr = _rand((n, ih, iw, cin), dev, 16).half(), pack_conv3x3(_rand((cout, cin, 3, 3), dev, 17, 0.05).cpu()).half().to(dev)
+    outs = []
+    for fam in (0, -1, 1, 2):
+        knobs(conv_win=fam)
+        o = torch.full((n, hw, cout), float("nan"), device=dev)
+        ops.conv3x3(xr, wr, upsample=up, bias=bias, out_f32=o)
+        outs.append(o)
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[2], outs[3])
+    assert rel_l2(outs[1], outs[0]) < 3e-6
+    knobs(conv_win=-1)
+    one = torch.full((1, hw, cout), float("nan"), device=dev)
+    ops.conv3x3(xr[-1:].contiguous(), wr, upsample=up, bias=bias, out_f32=one)
+    assert torch.equal(one[0], outs[1][-1])
+
+
 CONV_CASES = [  # n, ih, iw, cin, cout, stride, upsample
     (2, 9, 9, 64, 64, 1, False), (3, 16, 12, 128, 96, 1, False), (2, 16, 12, 64, 64, 2, False),
     (2, 9, 7, 64, 128, 2, False), (2, 8, 6, 64, 64, 1, True), (1, 5, 5, 192, 4, 1, False),
