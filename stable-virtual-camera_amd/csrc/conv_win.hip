@@ -476,7 +476,8 @@ int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
   if (a.stride != 1 || a.pad_lo != 1 || a.a2 != nullptr || a.sk_ws != nullptr) return 1;
   const int up = a.upsample ? 2 : 1;
   if (a.oh != up * a.ih || a.ow != up * a.iw || a.iw < 2 || a.ih < 2) return 1;
-  if (a.cin % 64 != 0 || (a.N % 160 != 0 && a.N % 128 != 0) || a.K != 9LL * a.cin) return 1;
+  const bool narrow = a.N <= 32 && a.N % 4 == 0;  // the UNet's head (4 channels), the VAE's conv_out
+  if (a.cin % 64 != 0 || (a.N % 160 != 0 && a.N % 128 != 0 && !narrow) || a.K != 9LL * a.cin) return 1;
   ConvWinGeom g{};
   g.Wp = a.iw + 1;             // padded SOURCE space (UP: the image before the nearest-2x upsample)
   g.Sp = (a.ih + 1) * g.Wp;
@@ -497,6 +498,14 @@ int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
   g.mul_sp = magic_u32((uint32_t)g.Sp);
   g.mul_wp = magic_u32((uint32_t)g.Wp);
   const bool stats = a.ch_stats != nullptr;
+  if (narrow) {
+    // a conv with a handful of output channels is bound by reading its input: the per-tap gather reads it nine times (head conv of a step:
+    // 346 us), the window once.  32-column tile (one MFMA block per wave column; the upper wave column idles when N <= 16)
+    if (stats || a.upsample) return 1;
+    int rc = launch_win<160, 32, 4, 320, false, false>(a, g, s);
+    if (rc == 1) rc = launch_win<128, 32, 4, 184, false, false, false, 16>(a, g, s);
+    return rc;
+  }
   if (a.N % 160 != 0) {
     // 128-column family (the VAE's 128 / 256 / 512 channels): linear tiles where the window fits (72 px rows), else 2-D tiles of 16 output
     // columns (144 .. 576 px rows).  Two 4-wave workgroups per CU on 128-row tiles: 2 - 11 % faster than the 8-wave 256-row tile on every

@@ -1049,7 +1049,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
   }
   // 3x3 / stride 1 / pad 1 convs whose tile window fits LDS: the input window (+ halo) is staged once per 64-channel slab and the nine
   // taps read it through shifted fragment addresses (conv_win.hip); everything else keeps the per-tap gather below
-  if (d->mode == 1 && !two_src && !narrow && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0 && g_seva_knobs.gemm_bm <= 0 &&
+  if (d->mode == 1 && !two_src && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_stagger < 0 && g_seva_knobs.gemm_bm <= 0 &&
       g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0) {
     const int rc = seva_conv_win_launch(a, s);
     if (rc <= 0) return rc;

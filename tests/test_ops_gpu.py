@@ -301,6 +301,26 @@ def test_conv3x3_window_kernel_128_columns_and_2d_tiles(dev, n, ih, iw, cin, cou
     assert torch.equal(one[0], outs[1][-1])
 
 
+@pytest.mark.parametrize("n,ih,iw,cin,cout", [(2, 72, 72, 128, 4), (3, 9, 9, 64, 4), (2, 36, 36, 128, 32), (1, 144, 144, 64, 8), (1, 160, 96, 64, 4)])
+def test_conv3x3_window_kernel_narrow_outputs(dev, n, ih, iw, cin, cout, knobs):
+    """Convs with a handful of output channels (reference model.py:170-174: the UNet's head, 320 -> 4; the VAE's conv_out) are bound
+    by reading their input; the 32-column family of the window kernel reads it once instead of nine times.  Integer data: bit-exact
+    against torch, linear and 2-D tiles, and equal to the per-tap kernel's result."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    hw = ih * iw
+    x = _ints((n, cin, ih, iw), -3, 3, dev, 21)
+    w = _ints((cout, cin, 3, 3), -2, 2, dev, 22)
+    bias, res = _ints((cout,), -4, 4, dev, 23), _ints((n, hw, cout), -5, 5, dev, 25)
+    ref = F.conv2d(x, w, bias, padding=1).permute(0, 2, 3, 1).reshape(n, hw, cout) + res
+    xh, wp = x.permute(0, 2, 3, 1).contiguous().half(), pack_conv3x3(w)
+    for fam in (-1, 0):
+        knobs(conv_win=fam)
+        out = torch.full((n, hw, cout), float("nan"), device=dev)
+        ops.conv3x3(xh, wp, bias=bias, residual=res, out_f32=out)
+        assert torch.equal(out, ref), f"conv_win {fam}: max diff {(out - ref).abs().max()}"
+
+
 CONV_CASES = [  # n, ih, iw, cin, cout, stride, upsample
     (2, 9, 9, 64, 64, 1, False), (3, 16, 12, 128, 96, 1, False), (2, 16, 12, 64, 64, 2, False),
     (2, 9, 7, 64, 128, 2, False), (2, 8, 6, 64, 64, 1, True), (1, 5, 5, 192, 4, 1, False),

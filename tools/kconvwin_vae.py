@@ -49,13 +49,15 @@ def exact_case(n, ih, iw, cin, cout, up, seed):
         ops.set_knob("conv_win", knob)
         out = torch.full((n, oh * ow, cout), float("nan"), device=dev)
         o16 = torch.full((n, oh * ow, cout), float("nan"), device=dev, dtype=torch.float16)
-        st = torch.full(ops.channel_stats_shape(M, cout), float("nan"), device=dev)
-        ops.conv3x3(xh, wp, bias=b, residual=res, out_f32=out, out_f16=o16, ch_stats=st, upsample=up)
+        narrow = cout <= 32
+        st = None if narrow else torch.full(ops.channel_stats_shape(M, cout), float("nan"), device=dev)
+        ops.conv3x3(xh, wp, bias=b, residual=res, out_f32=out, out_f16=None if narrow else o16, ch_stats=st, upsample=up)
         torch.cuda.synchronize()
-        ok = torch.equal(out, ref) and torch.equal(o16, ref.half())
-        nb = (oh * ow) // 64  # blocks per image: the consumer sums them per image
-        ssum = st[:, 0].view(n, nb, cout).sum(1)
-        ok = ok and torch.equal(ssum, ref.sum(1)) and torch.allclose(st[:, 1].view(n, nb, cout).double().sum(1), (ref.double() ** 2).sum(1), rtol=1e-6, atol=0)
+        ok = torch.equal(out, ref) and (narrow or torch.equal(o16, ref.half()))
+        if not narrow:
+            nb = (oh * ow) // 64  # blocks per image: the consumer sums them per image
+            ssum = st[:, 0].view(n, nb, cout).sum(1)
+            ok = ok and torch.equal(ssum, ref.sum(1)) and torch.allclose(st[:, 1].view(n, nb, cout).double().sum(1), (ref.double() ** 2).sum(1), rtol=1e-6, atol=0)
         if not ok:
             bad.append((knob, float((out - ref).abs().nan_to_num(1e9).max())))
     return bad
@@ -65,7 +67,8 @@ nbad = 0
 if not args.skip_exact:
     cases = [(2, 72, 72, 128, 128, False), (1, 144, 144, 64, 256, False), (2, 144, 144, 128, 128, False), (1, 288, 288, 64, 128, False),
              (1, 576, 576, 64, 128, False), (3, 32, 48, 64, 128, False), (2, 16, 16, 64, 384, False), (1, 160, 96, 64, 128, False),
-             (2, 72, 72, 64, 128, True), (1, 144, 144, 64, 256, True), (1, 288, 288, 64, 128, True), (3, 24, 40, 64, 128, True), (2, 8, 8, 128, 256, True)]
+             (2, 72, 72, 64, 128, True), (1, 144, 144, 64, 256, True), (1, 288, 288, 64, 128, True), (3, 24, 40, 64, 128, True), (2, 8, 8, 128, 256, True),
+             (2, 72, 72, 128, 4, False), (1, 576, 576, 64, 4, False), (3, 9, 9, 64, 4, False), (2, 36, 36, 128, 32, False), (1, 144, 144, 64, 8, False)]
     for k, c in enumerate(cases):
         bad = exact_case(*c, seed=300 + 7 * k)
         nbad += len(bad)
@@ -88,15 +91,16 @@ def timeit(fn, iters):
 print("== VAE decoder convs at 7 frames per pass: side cin cout up | us per-tap (TFLOP/s) | us window, default dispatch (TFLOP/s) | 4-wave family | 8-wave family", flush=True)
 tot = {0: 0.0, -1: 0.0, 1: 0.0, 2: 0.0}
 for side, cin, cout, up, calls in [(72, 512, 512, False, 9), (144, 512, 512, False, 6), (288, 512, 256, False, 1), (288, 256, 256, False, 5), (576, 256, 128, False, 1),
-                                   (576, 128, 128, False, 5), (72, 512, 512, True, 1), (144, 512, 512, True, 1), (288, 256, 256, True, 1)]:
-    n = 7
+                                   (576, 128, 128, False, 5), (72, 512, 512, True, 1), (144, 512, 512, True, 1), (288, 256, 256, True, 1), (576, 128, 4, False, 1), (-72, 640, 4, False, 0)]:
+    n = 7 if side > 0 else 42  # side < 0: the UNet's head conv at batch 42 (not part of a decode)
+    side = abs(side)
     s = 2 if up else 1
     M = n * (s * side) ** 2
     x = torch.randn(n, side, side, cin, device=dev, dtype=torch.float16)
     w = (torch.randn(cout, 9 * cin, device=dev) * 0.02).half()
     b = torch.randn(cout, device=dev)
     out = torch.empty(n, (s * side) ** 2, cout, device=dev)
-    st = torch.empty(ops.channel_stats_shape(M, cout), device=dev)
+    st = torch.empty(ops.channel_stats_shape(M, cout), device=dev) if cout > 32 else None
     best = {0: 1e30, -1: 1e30, 1: 1e30, 2: 1e30}
 
     def call(knob):
