@@ -54,7 +54,7 @@ for r in range(reps):
             if not torch.equal(snap[name], ref[name]):
                 bad[name] = bad.get(name, 0) + 1
                 break
-    if r % 50 == 0: print("run", r, "differing so far", nbad, flush=True)
+    if r % 10 == 0: print("run", r, "differing so far", nbad, flush=True)
 stop = True
 if th: th.join()
 print(f"forwards differing from the first: {nbad} of {reps - 1} | first differing buffer (count): {bad}", flush=True)
