@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised exactness fuzz of the implicit-GEMM 3x3 conv (integer data): sizes, stride 1/2, fused nearest-2x upsample,
-bottom/right-only padding, residual / row_add, tile shapes."""
+bottom/right-only padding, residual / row_add, tile shapes; every fourth case aims at the 128-column / 2-D-tile / 32-column families of the
+window-staged kernel (the VAE's shapes)."""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-virtual-camera_amd"))
@@ -39,6 +40,17 @@ for case in range(ncases):
         for k in kn:
             kn[k] = None
             ops.set_knob(k[5:].lower(), -1)
+    if case % 4 == 2:  # the window kernel's other families: 128 / 256 columns, rows wide enough for 2-D tiles, a handful of output channels
+        n = rng.choice([1, 2, 3])
+        ih, iw = rng.choice([8, 16, 24, 40, 64]), rng.choice([16, 32, 48, 80, 96, 160])
+        cin, cout = 64 * rng.choice([1, 2]), rng.choice([128, 256, 384, 4, 8, 32])
+        mode = rng.choice(["s1", "s1", "up"])
+        if mode == "up":
+            ih, iw = max(4, ih // 2), iw // 2
+        for k in kn:
+            kn[k] = None
+            ops.set_knob(k[5:].lower(), -1)
+        ops.set_knob("conv_win", rng.choice([-1, -1, 1, 2]))
     x, w, b = ints((n, cin, ih, iw), -3, 3), ints((cout, cin, 3, 3), -2, 2), ints((cout,), -4, 4)
     xi = F.interpolate(x, scale_factor=2, mode="nearest") if mode == "up" else x
     if mode == "s2br":
@@ -67,9 +79,14 @@ for case in range(ncases):
     if stats is not None:  # sums of small integers are exact in fp32 whatever the order; the sums of squares can pass 2^24
         M = n * oh * ow
         nb = stats.shape[0]
-        rp = torch.zeros(nb * 64, cout, device=dev); rp[:M] = refl.reshape(M, cout)
-        rp = rp.view(nb, 64, cout)
-        ok = ok and torch.equal(stats[:, 0], rp.sum(1)) and torch.allclose(stats[:, 1].double(), (rp.double() ** 2).sum(1), rtol=1e-5, atol=0)
+        if (oh * ow) % 64 == 0:  # the contract: the blocks of an image add up to the image (2-D tiles: a block is not 64 consecutive rows)
+            nbi = oh * ow // 64
+            ok = ok and torch.equal(stats[:, 0].view(n, nbi, cout).sum(1), refl.sum(1)) and \
+                torch.allclose(stats[:, 1].view(n, nbi, cout).double().sum(1), (refl.double() ** 2).sum(1), rtol=1e-5, atol=0)
+        else:
+            rp = torch.zeros(nb * 64, cout, device=dev); rp[:M] = refl.reshape(M, cout)
+            rp = rp.view(nb, 64, cout)
+            ok = ok and torch.equal(stats[:, 0], rp.sum(1)) and torch.allclose(stats[:, 1].double(), (rp.double() ** 2).sum(1), rtol=1e-5, atol=0)
     if not ok:
         bad += 1
         print("MISMATCH", case, n, ih, iw, cin, cout, mode, stats is not None, use_sk, {k: os.environ.get(k) for k in ("SEVA_GEMM_BN", "SEVA_GEMM_BM", "SEVA_GEMM_CHUNKS")}, flush=True)
