@@ -4,7 +4,10 @@
 // (tools/micro/pingpong_probe.hip); a 128 x 128 wave tile needs 0.25 LDS fragment reads per MFMA instead of 0.40 - 0.45 and 7.8 instead of
 // 12 - 14 KB of LDS-DMA per MFLOP -- the tile the vendor BLAS picks on these shapes (tools/kyardstick_blas.py: MT256x256x64).
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/gemm256_probe.hip -o /tmp/gemm256_probe && /tmp/gemm256_probe
-// C[m][n] = sum_k A[m][k] W[n][k], f16 in, fp32 accumulate, f16 out; K-tile 64 (128-byte LDS rows, source-side XOR swizzle), both operands
+// MODE 0: C[m][n] = sum_k A[m][k] W[n][k], one tile per workgroup, plain f16 store.  MODE 1: the GEGLU GEMM as the library computes it (W rows in
+// groups of 64 = [32 value | 32 gate], out[m][f] = v * gelu_erf(g), 16-byte stores through the paired row assignment) in a PERSISTENT loop: a
+// workgroup walks tiles id, id + grid, ...; the next tile's two stages are issued before the epilogue of the current one.
+// f16 in, fp32 accumulate, f16 out; K-tile 64 (128-byte LDS rows, source-side XOR swizzle), both operands
 // by LDS-DMA into two 64 KB stages; fragments of k-step u + 1 are read while the 64 MFMAs of k-step u run; one barrier per K-tile.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -24,6 +27,30 @@ static __device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds
 static __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   const int q = nb >> 3, r = nb & 7, x = bid & 7;
   return ((x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// value * gelu_erf(gate), erf by Abramowitz & Stegun 7.1.28 on packed fp32 (csrc/seva_common.h geglu2)
+static __device__ __forceinline__ f32x2 geglu2(f32x2 v, f32x2 g) {
+  const auto c2 = [](float c) { return f32x2{c, c}; };
+  const f32x2 z = __builtin_elementwise_abs(g) * 0.70710678118654752440f;
+  f32x2 q = __builtin_elementwise_fma(z, c2(0.0000430638f), c2(0.0002765672f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0001520143f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0092705272f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0422820123f));
+  q = __builtin_elementwise_fma(q, z, c2(0.0705230784f));
+  q = __builtin_elementwise_fma(q, z, c2(1.0f));
+  q = q * q; q = q * q; q = q * q; q = q * q;
+  const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  const f32x2 e = __builtin_elementwise_fma(r, c2(-1.0f), c2(1.0f));
+  const f32x2 es = {__builtin_copysignf(e[0], g[0]), __builtin_copysignf(e[1], g[1])};
+  const f32x2 h = g * 0.5f;
+  return v * __builtin_elementwise_fma(h, es, h);
+}
+static __device__ __forceinline__ f32x4 geglu4(f32x4 v, f32x4 g) {
+  const f32x2 lo = geglu2(f32x2{v[0], v[1]}, f32x2{g[0], g[1]}), hi = geglu2(f32x2{v[2], v[3]}, f32x2{g[2], g[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 constexpr int BM = 256, BN = 256, BK = 64, STAGE = (BM + BN) * 128;
@@ -129,6 +156,134 @@ __global__ __launch_bounds__(256, 1) void gemm256(const half_t* __restrict__ A, 
   }
 }
 
+
+// MODE 1: persistent GEGLU GEMM (see the header).  out[m][f], f < N / 2; W rows in groups of 64 = [32 value | 32 gate].
+__global__ __launch_bounds__(256, 1) void gemm256_geglu(const half_t* __restrict__ A, const half_t* __restrict__ W, half_t* __restrict__ C, int M, int N, int K,
+                                                        int tiles_m, int tiles_n, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, g = lane >> 4;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  const int sr = lane >> 3, sp = lane & 7;
+  const int row0 = 8 * wave + sr;
+  const int swz = sp ^ ((row0 >> 1) & 7);
+  const long step32 = 32L * K;
+  const int nk = K / BK, ntiles = tiles_m * tiles_n, G = gridDim.x;
+  // tile order: ids run down group_m M-tiles, then move to the next N-tile (the workgroups an XCD runs at a time share weight tiles AND panels)
+  auto tile_of = [&](int id, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n, grp = id / per_group, r = id - grp * per_group, first = grp * group_m;
+    const int gsz = tiles_m - first < group_m ? tiles_m - first : group_m;
+    tn = r / gsz;
+    tm = first + (r - tn * gsz);
+  };
+  int m0, n0;
+  const half_t *pa, *pw;
+  auto set_tile = [&](int id, int& m0_, int& n0_, const half_t*& pa_, const half_t*& pw_) {
+    int tm, tn;
+    tile_of(id, tm, tn);
+    m0_ = tm * BM;
+    n0_ = tn * BN;
+    pa_ = A + swz * 8;  // row offsets are added per piece (rows past M are clamped)
+    pw_ = W + (long)(n0_ + row0) * K + swz * 8;
+  };
+  auto issue = [&](int kt, int m0_, const half_t* pa_, const half_t* pw_) {
+    const unsigned dst = lds0 + (kt & 1) * STAGE + 8 * wave * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int r = m0_ + row0 + 32 * i;
+      if (r >= M) r = M - 1;
+      glds16_raw(pa_ + (long)r * K + (long)kt * BK, dst + i * 32 * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) glds16_raw(pw_ + i * step32 + (long)kt * BK, dst + BM * 128 + i * 32 * 128);
+  };
+  // fragment offsets inside a stage.  Activations: block b = rows 16 b + i16 of the wave's 128.  Weights (paired row assignment): MFMA row i16 =
+  // 4 g' + r' of block (q, t) is W row 64 q + 32 (t >= 2) + 8 g' + 4 (t & 1) + r': a lane then holds value and gate of features 32 q + 8 g .. + 7
+  int fw_row[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) fw_row[b] = 64 * (b >> 2) + ((b & 2) ? 32 : 0) + 8 * (i16 >> 2) + 4 * (b & 1) + (i16 & 3);
+  f32x4 acc[8][8];
+  half8_t fa[2][8], fw[2][8];
+  auto read_frags = [&](int set, int kt, int ks) {
+    const char* const sa = smem + (kt & 1) * STAGE + (wm * 128) * 128;
+    const char* const sw = smem + (kt & 1) * STAGE + BM * 128 + (wn * 128) * 128;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int row = 16 * b + i16;
+      fa[set][b] = *(const half8_t*)(sa + row * 128 + (((4 * ks + g) ^ ((row >> 1) & 7)) << 4));
+      const int rw = fw_row[b];
+      fw[set][b] = *(const half8_t*)(sw + rw * 128 + (((4 * ks + g) ^ ((rw >> 1) & 7)) << 4));
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[set][i]), "v"(fa[set][j]));
+  };
+  int id = xcd_remap(blockIdx.x, G);
+  if (id >= ntiles) return;
+  set_tile(id, m0, n0, pa, pw);
+  issue(0, m0, pa, pw);
+  if (nk > 1) issue(1, m0, pa, pw);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's first two stages (and the previous tile's stores) are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, 0);
+    const int nid = id + G;
+    int nm0 = 0, nn0 = 0;
+    const half_t *npa = pa, *npw = pw;
+    for (int kt = 0; kt < nk; ++kt) {
+      read_frags(1, kt, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue(kt + 2, m0, pa, pw);
+        read_frags(0, kt + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (nid < ntiles) {
+        // the last fragments are in registers: both stages are free; the NEXT tile's first two stages fly under the last MFMAs and the epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        set_tile(nid, nm0, nn0, npa, npw);
+        issue(0, nm0, npa, npw);
+        if (nk > 1) issue(1, nm0, npa, npw);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // epilogue: value * gelu(gate), 8 consecutive features per lane -> one 16-byte store per (row, 32-feature group)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int m = m0 + wm * 128 + 16 * j + i16;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 o0 = geglu4(acc[4 * q + 0][j], acc[4 * q + 2][j]);
+        const f32x4 o1 = geglu4(acc[4 * q + 1][j], acc[4 * q + 3][j]);
+        const half8_t h = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3], (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
+        if (m < M) *(half8_t*)(C + (long)m * (N / 2) + n0 / 2 + wn * 64 + 32 * q + 8 * g) = h;
+      }
+    }
+    if (nid >= ntiles) break;
+    id = nid;
+    m0 = nm0; n0 = nn0; pa = npa; pw = npw;
+  }
+}
+
 int main() {
   struct Shape { const char* name; int M, N, K; } shapes[] = {{"ds2 geglu", 54432, 5120, 640}, {"ds4 geglu", 13608, 10240, 1280}, {"ds2 qkv", 54432, 1920, 640},
                                                                {"ds4 ff2", 13608, 1280, 5120}, {"ds1 geglu", 217728, 2560, 320}, {"check", 700, 512, 192}};
@@ -172,6 +327,53 @@ int main() {
     }
     printf("%-10s M %6ld N %5ld K %4ld | %4d tiles = %.2f rounds of 256 | %8.1f us %7.1f TFLOP/s | worst rel err of 400 samples %.1e\n", s.name, M, N, K,
            tiles_m * tiles_n, tiles_m * tiles_n / 256.0, best * 1e3, 2.0 * M * N * K / best / 1e9, worst);
+    CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C));
+  }
+  // ---- MODE 1: persistent GEGLU ----
+  CK(hipFuncSetAttribute((const void*)gemm256_geglu, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  struct Shape2 { const char* name; int M, N, K; } gs[] = {{"ds2 geglu", 54432, 5120, 640}, {"ds4 geglu", 13608, 10240, 1280}, {"ds8 geglu", 3402, 10240, 1280}, {"check", 700, 512, 192}};
+  for (const Shape2& s2 : gs) {
+    const long M = s2.M, N = s2.N, K = s2.K;
+    std::vector<half_t> ha(M * K), hw(N * K);
+    srand(13);
+    for (auto& v : ha) v = (half_t)((rand() % 2001 - 1000) / 1000.f);
+    for (auto& v : hw) v = (half_t)((rand() % 2001 - 1000) / 4000.f);
+    half_t *A, *W, *C;
+    CK(hipMalloc(&A, M * K * 2)); CK(hipMalloc(&W, N * K * 2)); CK(hipMalloc(&C, M * (N / 2) * 2));
+    CK(hipMemcpy(A, ha.data(), M * K * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hw.data(), N * K * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(C, 0xff, M * (N / 2) * 2));
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)(N / BN), ntiles = tiles_m * tiles_n;
+    for (int gm : {1, 4, 8}) {
+      const int grid = ntiles < 256 ? ntiles : 256;
+      auto launch = [&]() { hipLaunchKernelGGL(gemm256_geglu, dim3(grid), dim3(256), 2 * STAGE, 0, A, W, C, (int)M, (int)N, (int)K, tiles_m, tiles_n, gm); };
+      launch();
+      CK(hipDeviceSynchronize());
+      std::vector<half_t> hc(M * (N / 2));
+      CK(hipMemcpy(hc.data(), C, M * (N / 2) * 2, hipMemcpyDeviceToHost));
+      double worst = 0;
+      for (int t = 0; t < 300; ++t) {
+        const long m = (t * 7919L + (t % 3 == 0 ? M - 1 - t : t * 131L)) % M, f = (t * 104729L + 17) % (N / 2);
+        const long rv = 64 * (f / 32) + f % 32, rg = rv + 32;
+        double v = 0, gt = 0;
+        for (long k = 0; k < K; ++k) { v += (double)ha[m * K + k] * (double)hw[rv * K + k]; gt += (double)ha[m * K + k] * (double)hw[rg * K + k]; }
+        const double ref = v * 0.5 * gt * (1.0 + erf(gt * 0.70710678118654752440));
+        const double err = fabs((double)hc[m * (N / 2) + f] - ref) / (fabs(ref) + 1.0);
+        if (err > worst) worst = err;
+      }
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      float best = 1e30f;
+      for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 10; ++i) launch();
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / 10 < best) best = ms / 10;
+      }
+      printf("GEGLU persistent %-10s M %6ld N %5ld K %4ld group_m %d | %4d tiles on %3d workgroups (max %d each) | %8.1f us %7.1f TFLOP/s | worst rel err of 300 samples %.1e\n",
+             s2.name, M, N, K, gm, ntiles, grid, (ntiles + grid - 1) / grid, best * 1e3, 2.0 * M * N * K / best / 1e9, worst);
+    }
     CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C));
   }
   return 0;
