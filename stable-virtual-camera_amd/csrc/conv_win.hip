@@ -54,7 +54,10 @@ struct ConvWinGeom {
 // is staged from the SOURCE image and tap (ky, kx) of output pixel (y, x) reads source pixel ((y + ky - 1) >> 1, (x + kx - 1) >> 1)
 // (A third weight stage with a counted vmcnt -- tap g + 2 issued under tap g, this tap's own DMA left in flight across the barrier -- was
 // built and measured on the 8-wave family: 3 - 10 % SLOWER on every shape, profiles/r04_kconvwin_variants.log; removed.)
-template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false, int TW = 0>
+// FP8 (BASELINE config 5; gemm.hip's e4m3 scheme): a 128-byte window / weight row is 128 e4m3 channels instead of 64 f16 ones (cin, K and the
+// pointers count 2-byte units, so every address here is unchanged); the two 16-byte fragment reads of a (tap, slab) form ONE 32-byte operand of
+// v_mfma_scale_f32_16x16x128_f8f6f4, the per-output-channel power-of-two weight scale rides as the E8M0 block scale of the weight operand.
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false, int TW = 0, bool FP8 = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWinGeom g) {
   constexpr bool T2D = TW > 0;
   static_assert(TW == 0 || TW == 16, "2-D tiles are 16 output columns wide: an MFMA block is a tile row");
@@ -231,6 +234,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   const int nslab = p.cin / BK;
   fill_window(0, 0);
   stage_w(0, 0);
+  // FP8: E8M0 scale bytes of this lane's weight rows (MFMA row fr of block j), four blocks per word (plain byte loads, retired below)
+  constexpr int NSC = (NJ + 3) / 4;
+  int wsc[FP8 ? NSC : 1];
+  if constexpr (FP8) {
+#pragma unroll
+    for (int w = 0; w < NSC; ++w) wsc[w] = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int64_t n = n0 + wn * WN + 16 * j + fr;
+      if (n >= p.N) n = p.N - 1;
+      wsc[j >> 2] |= (int)p.w_exp[n] << (8 * (j & 3));
+    }
+  }
 
   f32x4 acc[MI][NJ];
   if (p.residual) {  // the residual tile goes straight into the accumulators (clamped addresses; stores are guarded)
@@ -261,6 +277,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
+  if constexpr (FP8) {
+#pragma unroll
+    for (int w = 0; w < NSC; ++w) asm volatile("" : "+v"(wsc[w]));
+  }
 
   int cur = 0;  // weight stage of the K-tile being computed
   for (int s = 0; s < nslab; ++s) {
@@ -302,6 +322,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
 #pragma unroll
           for (int j = 0; j < NJ; ++j) bf[s2][j] = *(const half8_t*)(tb + b_off[s2] + j * 2048);
         if constexpr (FIRST) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FP8) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_f8(j, bf[0][j], bf[1][j], af[0][i], af[1][i], acc[i][j], wsc[j >> 2]);
+        } else {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -309,11 +335,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+        }
       };
-      if constexpr (NW == 4) {
+      if constexpr (NW == 4 && !FP8) {
         compute_tap(std::true_type{});
       } else {  // (giving the two wave groups of the 8-wave workgroup different orders under a wave-uniform branch spills 139+ registers)
         compute_tap(std::false_type{});
+      }
+      if constexpr (FP8) {  // pin the tap's MFMAs in front of its barrier: hipcc otherwise sinks all nine taps' scaled MFMAs behind the last
+                            // barrier of the slab and parks their fragments in scratch (2 KB; seen in the ISA)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
       }
       if constexpr (!DBW) {
         if (t == 8 && more) {  // every wave has read the last tap's fragments: the window is free for the next slab
@@ -400,7 +434,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
 
 uint32_t magic_u32(uint32_t d) { return (uint32_t)(0x100000000ull / d) + 1u; }
 
-template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false, int TW = 0>
+template <int BM, int BN, int NW, int WCAP, bool DBW, bool STATS, bool UP = false, int TW = 0, bool FP8 = false>
 int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
   constexpr int lds = (DBW ? 2 : 1) * WCAP * 128 + 2 * BN * 128;
   static_assert(lds <= 160 * 1024, "LDS per workgroup");
@@ -409,7 +443,7 @@ int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const uint64_t dev_bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_relaxed) & dev_bit)) {
-    (void)hipFuncSetAttribute((const void*)conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP, TW, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_devs.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   ConvWinGeom g = g0;
@@ -463,14 +497,14 @@ int launch_win(const GemmArgs& a, const ConvWinGeom& g0, hipStream_t s) {
     seva_set_error("conv_win: bad grid %lld", (long long)nb);
     return SEVA_ERR_ARG;
   }
-  hipLaunchKernelGGL((conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP, TW>), dim3((unsigned)nb), dim3(64 * NW), lds, s, a, g);
+  hipLaunchKernelGGL((conv_win_kernel<BM, BN, NW, WCAP, DBW, STATS, UP, TW, FP8>), dim3((unsigned)nb), dim3(64 * NW), lds, s, a, g);
   return seva_check_launch("conv_win_kernel");
 }
 
 }  // namespace
 
 // 0 = launched, 1 = not applicable (the caller uses the per-tap gather of gemm.hip), < 0 = error
-int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
+int seva_conv_win_launch(const GemmArgs& a, hipStream_t s, bool fp8) {
   const int knob = g_seva_knobs.conv_win;
   if (knob == 0) return 1;
   if (a.stride != 1 || a.pad_lo != 1 || a.a2 != nullptr || a.sk_ws != nullptr) return 1;
@@ -498,6 +532,16 @@ int seva_conv_win_launch(const GemmArgs& a, hipStream_t s) {
   g.mul_sp = magic_u32((uint32_t)g.Sp);
   g.mul_wp = magic_u32((uint32_t)g.Wp);
   const bool stats = a.ch_stats != nullptr;
+  if (fp8) {
+    // e4m3 operands (the C >= 640 levels in fp8 mode): 128-column tiles only (with 160 columns the 8-register operand tuples of the scaled
+    // MFMA no longer fit beside 100 accumulators: 2 KB of scratch; gemm.hip's e4m3 kernels found the same); cin counts 2-byte units
+    if (a.N % 128 != 0 || a.w_exp == nullptr) return 1;
+    const bool eight = knob == 2;  // two 4-wave workgroups per CU are faster on every e4m3 shape of a step (profiles/r04_kconvwin_fp8.log)
+    if (a.upsample) return 1;  // (the engine keeps the three upsample convs in f16)
+    int rc = eight ? launch_win<256, 128, 8, 416, true, true, false, 0, true>(a, g, s) : launch_win<128, 128, 4, 288, false, true, false, 0, true>(a, g, s);
+    if (rc == 1) rc = eight ? launch_win<128, 128, 4, 288, false, true, false, 0, true>(a, g, s) : launch_win<256, 128, 8, 416, true, true, false, 0, true>(a, g, s);
+    return rc;
+  }
   if (narrow) {
     // a conv with a handful of output channels is bound by reading its input: the per-tap gather reads it nine times (head conv of a step:
     // 346 us), the window once.  32-column tile (one MFMA block per wave column; the upper wave column idles when N <= 16)

@@ -45,25 +45,7 @@ __device__ __forceinline__ void wait_vm() {
 // weight operand (every k-block of row n carries 127 + e[n]; measured: tools/micro/mfma_fp8_scale_map2.hip), the
 // activation operand has unit scale: the accumulator holds the de-quantised product, so every epilogue
 // (residual-in-accumulator, GEGLU, column scale) is the f16 kernel's.
-typedef int v8i_t __attribute__((ext_vector_type(8)));
-template <int OPSEL>
-__device__ __forceinline__ f32x4 mfma_f8_sel(half8_t w_lo, half8_t w_hi, half8_t a_lo, half8_t a_hi, f32x4 c, int wscale) {
-  typedef int v4i_t __attribute__((ext_vector_type(4)));
-  const v4i_t wl = __builtin_bit_cast(v4i_t, w_lo), wh = __builtin_bit_cast(v4i_t, w_hi);
-  const v4i_t al = __builtin_bit_cast(v4i_t, a_lo), ah = __builtin_bit_cast(v4i_t, a_hi);
-  const v8i_t w = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
-  const v8i_t a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0 /*e4m3*/, 0 /*e4m3*/, OPSEL, wscale, 0, 0x7F7F7F7F);
-}
-// scale byte (j & 3) of the packed per-lane scale word of block j
-__device__ __forceinline__ f32x4 mfma_f8(int j, half8_t w_lo, half8_t w_hi, half8_t a_lo, half8_t a_hi, f32x4 c, int wscale) {
-  switch (j & 3) {
-    case 0: return mfma_f8_sel<0>(w_lo, w_hi, a_lo, a_hi, c, wscale);
-    case 1: return mfma_f8_sel<1>(w_lo, w_hi, a_lo, a_hi, c, wscale);
-    case 2: return mfma_f8_sel<2>(w_lo, w_hi, a_lo, a_hi, c, wscale);
-    default: return mfma_f8_sel<3>(w_lo, w_hi, a_lo, a_hi, c, wscale);
-  }
-}
+// (mfma_f8: gemm_common.h)
 
 // NW: waves per workgroup.  4 (2 x 2 wave tiles, two workgroups per CU) everywhere in production; the experimental library also
 // instantiates 8 (2 x 4 wave tiles, ONE workgroup per CU): two N-sibling 128 x 160 tiles fused so that their A rows are staged once
@@ -1019,6 +1001,11 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
     if (d->mode == 0) {
       if (half_m8) return wide8 ? launch<64, 160, 0, 0, true>(a, s) : launch<64, 128, 0, 0, true>(a, s);
       return launch<128, 128, 0, 0, true>(a, s);
+    }
+    // 3x3 / stride 1 / pad 1 convs: the window-staged kernel (conv_win.hip, e4m3 instantiations of its 160-column family)
+    if (d->mode == 1 && d->a2 == nullptr && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0) {
+      const int rc = seva_conv_win_launch(a, s, true);
+      if (rc <= 0) return rc;
     }
     if (half_m8) return wide8 ? launch<64, 160, 1, 0, true>(a, s) : launch<64, 128, 1, 0, true>(a, s);
     return launch<128, 128, 1, 0, true>(a, s);

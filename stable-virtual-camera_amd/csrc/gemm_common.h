@@ -105,4 +105,26 @@ static __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // conv_win.hip: 3x3 / stride 1 / pad 1 conv with the tile's input window staged in LDS.  0 = launched, 1 = not applicable, < 0 = error
-int seva_conv_win_launch(const GemmArgs& a, hipStream_t s);
+// e4m3 x e4m3 -> fp32 on the block-scaled MFMA (gemm.hip: FP8); wscale = four packed E8M0 weight-scale bytes, OPSEL picks one
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+template <int OPSEL>
+static __device__ __forceinline__ f32x4 mfma_f8_sel(half8_t w_lo, half8_t w_hi, half8_t a_lo, half8_t a_hi, f32x4 c, int wscale) {
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  const v4i_t wl = __builtin_bit_cast(v4i_t, w_lo), wh = __builtin_bit_cast(v4i_t, w_hi);
+  const v4i_t al = __builtin_bit_cast(v4i_t, a_lo), ah = __builtin_bit_cast(v4i_t, a_hi);
+  const v8i_t w = {wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
+  const v8i_t a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0 /*e4m3*/, 0 /*e4m3*/, OPSEL, wscale, 0, 0x7F7F7F7F);
+}
+// scale byte (j & 3) of the packed per-lane scale word of block j
+static __device__ __forceinline__ f32x4 mfma_f8(int j, half8_t w_lo, half8_t w_hi, half8_t a_lo, half8_t a_hi, f32x4 c, int wscale) {
+  switch (j & 3) {
+    case 0: return mfma_f8_sel<0>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+    case 1: return mfma_f8_sel<1>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+    case 2: return mfma_f8_sel<2>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+    default: return mfma_f8_sel<3>(w_lo, w_hi, a_lo, a_hi, c, wscale);
+  }
+}
+
+
+int seva_conv_win_launch(const GemmArgs& a, hipStream_t s, bool fp8 = false);

@@ -124,6 +124,32 @@ def test_conv3x3_fp8_exact(dev, n, ih, iw, cin, cout, stride):
     assert torch.equal(got, ref), f"max diff {(got - ref).abs().max()}"
 
 
+@pytest.mark.parametrize("n,ih,iw,cin,cout,stats", [(3, 8, 8, 640, 640, False), (42, 9, 9, 128, 1280, False), (2, 36, 36, 128, 640, False),
+                                                    (2, 72, 72, 128, 128, True), (1, 33, 31, 128, 256, False), (2, 16, 16, 256, 384, True)])
+def test_conv3x3_fp8_window_kernel(dev, n, ih, iw, cin, cout, stats, knobs):
+    """The window-staged conv on e4m3 operands (csrc/conv_win.hip, FP8 instantiations of its 128-column family: what the C >= 640 convs of
+    a step run in fp8 mode): a window / weight row is 128 e4m3 channels, the two fragment halves of a (tap, slab) form one operand of the
+    block-scaled MFMA.  Integer data with power-of-two weight scales: bit-exact against torch for the default dispatch, both families
+    and the per-tap kernel; GroupNorm statistics add up per image."""
+    from seva import ops
+    from seva._engine import pack_conv3x3
+    x = _ints((n, cin, ih, iw), -3, 3, dev, 31)
+    w = _ints((cout, cin, 3, 3), -2, 2, dev, 32)
+    g = torch.Generator().manual_seed(33)
+    e = torch.randint(-2, 3, (cout,), generator=g).to(dev)
+    bias, res = _ints((cout,), -4, 4, dev, 34), _ints((n, ih * iw, cout), -5, 5, dev, 35)
+    ref = F.conv2d(x, w * torch.exp2(e.float())[:, None, None, None], bias, padding=1).permute(0, 2, 3, 1).reshape(n, ih * iw, cout) + res
+    x8, w8 = _f8(x.permute(0, 2, 3, 1).contiguous()), _f8(pack_conv3x3(w).float())
+    for fam in (-1, 1, 2, 0):
+        knobs(conv_win=fam)
+        out = torch.full((n, ih * iw, cout), float("nan"), device=dev)
+        st = torch.full(ops.channel_stats_shape(n * ih * iw, cout), float("nan"), device=dev) if stats else None
+        ops.conv3x3(x8, w8, w_exp=(e + 127).to(U8), bias=bias, residual=res, out_f32=out, ch_stats=st)
+        assert torch.equal(out, ref), f"conv_win {fam}: max diff {(out - ref).abs().max()}"
+        if st is not None:
+            assert torch.equal(st[:, 0].view(n, ih * iw // 64, cout).sum(1), ref.sum(1))
+
+
 def _close_fp8(got_u8, ref_f32):
     """e4m3 bytes vs an fp32 reference: equal to torch's cast except where fp32 arithmetic differences cross a rounding tie."""
     got = got_u8.view(torch.float8_e4m3fn).float()
