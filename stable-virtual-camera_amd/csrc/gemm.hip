@@ -91,7 +91,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   constexpr bool STATS_OK = EPI == 0 && !PAIRED && !ASTAT && !DBGK && WM == 64 && NJ >= 4;
   // order of the fragment reads (see ktile): measured per kernel family, same box (profiles/r04_ab_gemm_frags_first.log): the f16-only /
   // GEGLU kernels gain 2 - 5 % (36x36 GEGLU 419 -> 399 us), the fp32-output 160 x 160 kernels LOSE 5 % with the half measure their registers allow
+#ifdef SEVA_FF_PLAIN
+  constexpr int FRAGS_FIRST = (DBGK || FP8 || ASTAT) ? 0 : !PAIRED ? SEVA_FF_PLAIN : BN == 160 ? 1 : 2;
+#else
   constexpr int FRAGS_FIRST = (DBGK || FP8 || ASTAT || !PAIRED) ? 0 : BN == 160 ? 1 : 2;
+#endif
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [A buf0][A buf1][B buf0][B buf1]
@@ -485,6 +489,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = mfma_f8(j, bf[0][j], bf[1][j], af[0][i], af[1][i], acc[i][j], wsc[j >> 2]);
+        // the K-tile's scaled MFMAs stay in front of its barrier: hipcc otherwise sinks half of them behind it, their fragments with them
+        // (conv_win.hip met the extreme form).  Same-box A/B of the fp8 step, two interleaved rounds: GEMM class 36.95 -> 36.14 ms
+        // (profiles/r04_ab_fp8_mfma_pin.log); 128 x 160 e4m3 tiles then compile with 13 - 19 dwords of scratch and gain nothing more
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
       } else
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -501,6 +512,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[s][j]));
         }
       }
+#ifdef SEVA_F16_PIN  // A/B only: the f16 MFMAs of a K-tile pinned in front of its barrier (hipcc leaves 15 of 50 behind it on the 160 x 160 kernels)
+      if constexpr (!PAIRED && !FP8 && !DBGK) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
+      }
+#endif
       }  // !ASTAT
       if (ASYNC) {
         // K-tile kt+1 must have landed.  It was issued before the old stores when kt == 0 (they stay
@@ -1002,7 +1021,7 @@ int gemm_entry(const seva_gemm_desc* d, seva_stream_t stream) {
       if (half_m8) return wide8 ? launch<64, 160, 0, 0, true>(a, s) : launch<64, 128, 0, 0, true>(a, s);
       return launch<128, 128, 0, 0, true>(a, s);
     }
-    // 3x3 / stride 1 / pad 1 convs: the window-staged kernel (conv_win.hip, e4m3 instantiations of its 160-column family)
+    // 3x3 / stride 1 / pad 1 convs: the window-staged kernel (conv_win.hip, e4m3 instantiations of its 128-column family)
     if (d->mode == 1 && d->a2 == nullptr && g_seva_knobs.gemm_dbg < 0 && g_seva_knobs.gemm_bm <= 0 && g_seva_knobs.gemm_bn <= 0 && g_seva_knobs.gemm_chunks <= 0) {
       const int rc = seva_conv_win_launch(a, s, true);
       if (rc <= 0) return rc;
