@@ -91,11 +91,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
   constexpr bool STATS_OK = EPI == 0 && !PAIRED && !ASTAT && !DBGK && WM == 64 && NJ >= 4;
   // order of the fragment reads (see ktile): measured per kernel family, same box (profiles/r04_ab_gemm_frags_first.log): the f16-only /
   // GEGLU kernels gain 2 - 5 % (36x36 GEGLU 419 -> 399 us), the fp32-output 160 x 160 kernels LOSE 5 % with the half measure their registers allow
-#ifdef SEVA_FF_PLAIN
-  constexpr int FRAGS_FIRST = (DBGK || FP8 || ASTAT) ? 0 : !PAIRED ? SEVA_FF_PLAIN : BN == 160 ? 1 : 2;
-#else
   constexpr int FRAGS_FIRST = (DBGK || FP8 || ASTAT || !PAIRED) ? 0 : BN == 160 ? 1 : 2;
-#endif
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [A buf0][A buf1][B buf0][B buf1]
@@ -512,14 +508,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_kernel(GemmArgs p) {
           for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[s][j]));
         }
       }
-#ifdef SEVA_F16_PIN  // A/B only: the f16 MFMAs of a K-tile pinned in front of its barrier (hipcc leaves 15 of 50 behind it on the 160 x 160 kernels)
+      // the K-tile's MFMAs stay in front of its barrier: left alone, hipcc leaves 15 of the 50 (160 x 160) behind it, their fragments live across
+      // the barrier.  Same-box A/B, three interleaved rounds of the step: GEMM class 43.57 -> 43.17 ms (profiles/r04_ab_gemm_mfma_pin.log)
       if constexpr (!PAIRED && !FP8 && !DBGK) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[i][j]));
       }
-#endif
       }  // !ASTAT
       if (ASYNC) {
         // K-tile kt+1 must have landed.  It was issued before the old stores when kt == 0 (they stay
