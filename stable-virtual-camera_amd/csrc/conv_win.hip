@@ -342,11 +342,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_win_kernel(GemmArgs p, ConvWi
       } else {  // (giving the two wave groups of the 8-wave workgroup different orders under a wave-uniform branch spills 139+ registers)
         compute_tap(std::false_type{});
       }
-#ifdef SEVA_CW8_PIN
-      if constexpr (FP8 || NW == 8) {
-#else
-      if constexpr (FP8) {  // pin the tap's MFMAs in front of its barrier
-#endif: hipcc otherwise sinks all nine taps' scaled MFMAs behind the last
+      if constexpr (FP8) {  // pin the tap's MFMAs in front of its barrier (the same pin on the f16 8-wave family: conv class +0.3 ms, not done): hipcc otherwise sinks all nine taps' scaled MFMAs behind the last
                             // barrier of the slab and parks their fragments in scratch (2 KB; seen in the ISA)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
